@@ -1,0 +1,166 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/_build/liboracle.so (the plain-C CPU restatement of the reference's
+canonical-Huffman path, oracle/huff_oracle.c) plus a thin runner for oracle/_ref/ref_glzip (the
+reference's own headers compiled in the build container, when present).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module --
+as the checker, never as the product.  The product (golden-huffman_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
+REF_BIN = os.path.join(HERE, "_ref", "ref_glzip")
+NSYM = 257
+
+
+class OrcCode(C.Structure):
+    """mirror of orc_code (include/canonical_huff_encoder.h:107-120 of the reference)."""
+
+    _fields_ = [
+        ("length", C.c_uint32 * NSYM),
+        ("codeword", C.c_uint32 * NSYM),
+        ("symbol", C.c_uint32 * NSYM),
+        ("first_code", C.c_uint32 * 64),
+        ("start_pos", C.c_uint32 * 64),
+        ("min_len", C.c_int32),
+        ("max_len", C.c_int32),
+    ]
+
+    def as_dict(self):
+        ml = self.max_len
+        return {
+            "length": list(self.length),
+            "codeword": list(self.codeword),
+            "symbol": list(self.symbol),
+            "first_code": list(self.first_code)[1 : ml + 1],
+            "start_pos": list(self.start_pos)[1 : ml + 1],
+            "min_len": self.min_len,
+            "max_len": ml,
+        }
+
+
+def build():
+    """(re)build liboracle.so -- and the reference driver when /root/reference is present."""
+    subprocess.run(["make", "-s", "-C", HERE, "all"], check=True)
+    if os.path.isdir("/root/reference/include"):
+        subprocess.run(["make", "-s", "-C", HERE, "ref"], check=True)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        u8p = C.c_void_p
+        L.orc_histogram.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_int64)]
+        L.orc_histogram.restype = None
+        L.orc_build_code.argtypes = [C.POINTER(C.c_int64), C.POINTER(OrcCode)]
+        L.orc_build_code.restype = C.c_int
+        L.orc_header_size.argtypes = [C.POINTER(OrcCode)]
+        L.orc_header_size.restype = C.c_size_t
+        L.orc_write_header.argtypes = [C.POINTER(OrcCode), u8p]
+        L.orc_write_header.restype = C.c_size_t
+        L.orc_encode_body.argtypes = [u8p, C.c_size_t, C.POINTER(OrcCode), u8p, C.c_size_t]
+        L.orc_encode_body.restype = C.c_size_t
+        L.orc_compress.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_compress.restype = C.c_int
+        L.orc_compress_bound.argtypes = [C.c_size_t]
+        L.orc_compress_bound.restype = C.c_size_t
+        L.orc_parse_header.argtypes = [u8p, C.c_size_t, C.POINTER(OrcCode)]
+        L.orc_parse_header.restype = C.c_size_t
+        L.orc_decode_body.argtypes = [u8p, C.c_size_t, C.POINTER(OrcCode), u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_decode_body.restype = C.c_int
+        L.orc_decompress.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_decompress.restype = C.c_int
+        L.orc_body_bits.argtypes = [C.POINTER(C.c_int64), C.POINTER(OrcCode)]
+        L.orc_body_bits.restype = C.c_uint64
+        _lib = L
+    return _lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data
+
+
+def histogram(data):
+    a, p = _u8(data)
+    h = np.zeros(NSYM, dtype=np.int64)
+    lib().orc_histogram(p, a.size, h.ctypes.data_as(C.POINTER(C.c_int64)))
+    return h
+
+
+def build_code(hist):
+    h = np.ascontiguousarray(hist, dtype=np.int64)
+    c = OrcCode()
+    rc = lib().orc_build_code(h.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(c))
+    if rc:
+        raise ValueError("orc_build_code rc=%d" % rc)
+    return c
+
+
+def header_bytes(code):
+    n = lib().orc_header_size(C.byref(code))
+    out = np.zeros(n, dtype=np.uint8)
+    w = lib().orc_write_header(C.byref(code), out.ctypes.data)
+    assert w == n
+    return out
+
+
+def body_bits(hist, code):
+    h = np.ascontiguousarray(hist, dtype=np.int64)
+    return int(lib().orc_body_bits(h.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(code)))
+
+
+def compress(data):
+    a, p = _u8(data)
+    cap = lib().orc_compress_bound(a.size)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().orc_compress(p, a.size, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        raise ValueError("orc_compress rc=%d" % rc)
+    return out[: n.value].copy()
+
+
+def decompress(crs2, cap=None):
+    a, p = _u8(crs2)
+    if cap is None:
+        cap = a.size * 8 + 64  # min code length is 1 bit
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().orc_decompress(p, a.size, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        raise ValueError("orc_decompress rc=%d" % rc)
+    return out[: n.value].copy()
+
+
+def parse_header(crs2):
+    a, p = _u8(crs2)
+    c = OrcCode()
+    hs = lib().orc_parse_header(p, a.size, C.byref(c))
+    if not hs:
+        raise ValueError("bad .crs2 header")
+    return c, hs
+
+
+# ------------------------------------------------------------------ the compiled reference (build container only)
+def have_ref():
+    return os.path.exists(REF_BIN)
+
+
+def ref_run(args, timeout=120):
+    """run oracle/_ref/ref_glzip under a timeout and an output-size limit (a runaway
+    reference decoder fills the disk)."""
+    cmd = "ulimit -f 16777216; exec '%s' %s" % (REF_BIN, " ".join("'%s'" % a for a in args))
+    return subprocess.run(["bash", "-c", cmd], check=True, timeout=timeout, capture_output=True, text=True).stdout
