@@ -1,0 +1,464 @@
+// golden-huffman_amd/csrc/ghf_api.hip -- the C ABI of include/ghf.h on top of the gfx950 kernels.
+// Host-side only: argument checks, workspace, launches.  No compute happens on the CPU here except
+// ghf_parse_header (a <= 1.3 KiB header; SURVEY 8 row a7 keeps it on the host).
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "ghf_internal.h"
+
+using namespace ghf;
+
+struct ghf_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  int* d_status = nullptr;
+  int* h_status = nullptr;  // pinned
+  // workspace
+  uint32_t* d_chunk_hist = nullptr;
+  size_t chunk_hist_cap = 0;  // in chunks
+  uint64_t* d_chunk_off = nullptr;
+  size_t chunk_off_cap = 0;  // in entries
+  const uint8_t* hist_in = nullptr;  // what d_chunk_hist currently describes
+  uint64_t hist_n = 0;
+  uint32_t hist_chunk_log2 = 0;
+  const uint8_t* plan_in = nullptr;  // what d_chunk_off currently describes
+  uint64_t plan_n = 0;
+  const ghf_code* plan_code = nullptr;
+  uint64_t* d_hist = nullptr;   // [257]
+  ghf_code* d_code = nullptr;   // scratch tables for ghf_compress
+  DecTables* d_dt = nullptr;
+  uint64_t* d_u64 = nullptr;    // [8] scratch scalars: 0 total_bits, 1..2 end, ...
+  std::string err;
+};
+
+namespace {
+
+int fail(ghf_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) {
+      c->err += ": ";
+      c->err += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+
+#define GHF_HIP(c, call)                                         \
+  do {                                                           \
+    hipError_t e_ = (call);                                      \
+    if (e_ != hipSuccess) return fail((c), GHF_E_HIP, #call, e_); \
+  } while (0)
+
+int ensure_ws(ghf_ctx* c, size_t nchunks) {
+  if (nchunks + 1 > c->chunk_off_cap) {
+    if (c->d_chunk_off) (void)hipFree(c->d_chunk_off);
+    c->d_chunk_off = nullptr;
+    c->chunk_off_cap = 0;
+    size_t cap = std::max<size_t>(nchunks + 1, 1024);
+    GHF_HIP(c, hipMalloc(&c->d_chunk_off, cap * sizeof(uint64_t)));
+    c->chunk_off_cap = cap;
+    c->plan_in = nullptr;
+  }
+  if (nchunks > c->chunk_hist_cap) {
+    if (c->d_chunk_hist) (void)hipFree(c->d_chunk_hist);
+    c->d_chunk_hist = nullptr;
+    c->chunk_hist_cap = 0;
+    size_t cap = std::max<size_t>(nchunks, 1024);
+    GHF_HIP(c, hipMalloc(&c->d_chunk_hist, cap * 256 * sizeof(uint32_t)));
+    c->chunk_hist_cap = cap;
+    c->hist_in = nullptr;
+  }
+  return GHF_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int ghf_version(void) { return 100; }
+
+const char* ghf_status_string(int s) {
+  switch (s) {
+    case GHF_OK: return "ok";
+    case GHF_E_INVAL: return "invalid argument";
+    case GHF_E_HIP: return "HIP runtime error / no device";
+    case GHF_E_EMPTY: return "empty input (undefined in the reference)";
+    case GHF_E_CODELEN: return "code longer than 32 bits (reference limit)";
+    case GHF_E_CAP: return "output capacity too small";
+    case GHF_E_FORMAT: return "not a .crs2 header";
+    case GHF_E_CORRUPT: return "corrupt stream";
+    case GHF_E_NOMEM: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+int ghf_ctx_create(int device, ghf_ctx** out) {
+  if (!out) return GHF_E_INVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GHF_E_HIP;  // no CPU fallback, by design
+  if (device < 0 || device >= ndev) return GHF_E_INVAL;
+  ghf_ctx* c = new (std::nothrow) ghf_ctx();
+  if (!c) return GHF_E_NOMEM;
+  c->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&c->d_status, sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc(&c->h_status, sizeof(int), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(&c->d_hist, GHF_NSYM * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMalloc(&c->d_code, sizeof(ghf_code));
+  if (e == hipSuccess) e = hipMalloc(&c->d_dt, sizeof(DecTables));
+  if (e == hipSuccess) e = hipMalloc(&c->d_u64, 8 * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMemset(c->d_status, 0, sizeof(int));
+  if (e != hipSuccess) {
+    ghf_ctx_destroy(c);
+    return GHF_E_HIP;
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return GHF_OK;
+}
+
+int ghf_ctx_destroy(ghf_ctx* c) {
+  if (!c) return GHF_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->d_status) (void)hipFree(c->d_status);
+  if (c->h_status) (void)hipHostFree(c->h_status);
+  if (c->d_chunk_hist) (void)hipFree(c->d_chunk_hist);
+  if (c->d_chunk_off) (void)hipFree(c->d_chunk_off);
+  if (c->d_hist) (void)hipFree(c->d_hist);
+  if (c->d_code) (void)hipFree(c->d_code);
+  if (c->d_dt) (void)hipFree(c->d_dt);
+  if (c->d_u64) (void)hipFree(c->d_u64);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return GHF_OK;
+}
+
+int ghf_ctx_set_stream(ghf_ctx* c, void* hip_stream) {
+  if (!c) return GHF_E_INVAL;
+  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return GHF_OK;
+}
+
+int ghf_sync(ghf_ctx* c) {
+  if (!c) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  GHF_HIP(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  GHF_HIP(c, hipStreamSynchronize(c->stream));
+  const int s = *c->h_status;
+  if (s != GHF_OK) c->err = ghf_status_string(s);
+  return s;
+}
+
+int ghf_status(ghf_ctx* c) { return ghf_sync(c); }
+
+int ghf_clear_status(ghf_ctx* c) {
+  if (!c) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  GHF_HIP(c, hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
+  c->err.clear();
+  return GHF_OK;
+}
+
+const char* ghf_last_error(ghf_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// ---------------------------------------------------------------------------------------------- memory
+int ghf_device_alloc(ghf_ctx* c, size_t bytes, void** d_ptr) {
+  if (!c || !d_ptr) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  GHF_HIP(c, hipMalloc(d_ptr, bytes ? bytes : 16));
+  return GHF_OK;
+}
+int ghf_device_free(ghf_ctx* c, void* d_ptr) {
+  if (!c) return GHF_E_INVAL;
+  if (d_ptr) {
+    GHF_HIP(c, hipSetDevice(c->device));
+    GHF_HIP(c, hipStreamSynchronize(c->stream));
+    GHF_HIP(c, hipFree(d_ptr));
+  }
+  return GHF_OK;
+}
+int ghf_host_alloc(ghf_ctx* c, size_t bytes, void** h_ptr) {
+  if (!c || !h_ptr) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  GHF_HIP(c, hipHostMalloc(h_ptr, bytes ? bytes : 16, hipHostMallocDefault));
+  return GHF_OK;
+}
+int ghf_host_free(ghf_ctx* c, void* h_ptr) {
+  if (!c) return GHF_E_INVAL;
+  if (h_ptr) GHF_HIP(c, hipHostFree(h_ptr));
+  return GHF_OK;
+}
+int ghf_copy_h2d(ghf_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+  if (!c || (bytes && (!d_dst || !h_src))) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  if (bytes) GHF_HIP(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+  return GHF_OK;
+}
+int ghf_copy_d2h(ghf_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+  if (!c || (bytes && (!h_dst || !d_src))) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  if (bytes) GHF_HIP(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+  return GHF_OK;
+}
+int ghf_memset_d(ghf_ctx* c, void* d_dst, int value, size_t bytes) {
+  if (!c || (bytes && !d_dst)) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  if (bytes) GHF_HIP(c, hipMemsetAsync(d_dst, value, bytes, c->stream));
+  return GHF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- encode
+uint32_t ghf_chunk_symbols(size_t n) { return 1u << chunk_log2_for(n); }
+size_t ghf_header_bytes(int max_len) { return 1040 + 8 * (size_t)max_len; }
+
+size_t ghf_compress_bound(size_t n) {
+  // header (max_len <= 32) + 9 bits per symbol (a 257-symbol Huffman code never loses to the 9-bit
+  // fixed-length code) + end mark, rounded up to whole 16-byte units + one spare unit
+  const size_t bits = 9 * (n + 1);
+  size_t b = 1040 + 8 * 32 + (bits + 7) / 8;
+  return ((b + 15) & ~(size_t)15) + 16;
+}
+
+int ghf_histogram(ghf_ctx* c, const uint8_t* d_in, size_t n, uint64_t* d_hist) {
+  if (!c || !d_hist || (n && !d_in)) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  const uint32_t cl = chunk_log2_for(n);
+  const size_t nchunks = (n + ((size_t)1 << cl) - 1) >> cl;
+  int rc = ensure_ws(c, nchunks);
+  if (rc) return rc;
+  launch_histogram(d_in, n, cl, (uint32_t)nchunks, c->d_chunk_hist, d_hist, c->stream);
+  GHF_HIP(c, hipGetLastError());
+  c->hist_in = d_in;
+  c->hist_n = n;
+  c->hist_chunk_log2 = cl;
+  return GHF_OK;
+}
+
+int ghf_build_code(ghf_ctx* c, const uint64_t* d_hist, ghf_code* d_code) {
+  if (!c || !d_hist || !d_code) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  launch_build_code(d_hist, d_code, c->d_status, c->stream);
+  GHF_HIP(c, hipGetLastError());
+  if (c->plan_code == d_code) c->plan_in = nullptr;  // tables changed: any cached plan is stale
+  return GHF_OK;
+}
+
+int ghf_write_header(ghf_ctx* c, const ghf_code* d_code, uint8_t* d_out, size_t cap) {
+  if (!c || !d_code || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 3u)) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  launch_write_header(d_code, d_out, cap, c->d_status, c->stream);
+  GHF_HIP(c, hipGetLastError());
+  return GHF_OK;
+}
+
+int ghf_encode_plan(ghf_ctx* c, const uint8_t* d_in, size_t n, const ghf_code* d_code, uint64_t* d_total_bits) {
+  if (!c || !d_code || (n && !d_in)) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  const uint32_t cl = chunk_log2_for(n);
+  const size_t nchunks = (n + ((size_t)1 << cl) - 1) >> cl;
+  int rc = ensure_ws(c, nchunks);
+  if (rc) return rc;
+  const bool have_hist = c->hist_in == d_in && c->hist_n == n && c->hist_chunk_log2 == cl && n != 0;
+  launch_plan(d_in, n, cl, (uint32_t)nchunks, have_hist ? c->d_chunk_hist : nullptr, d_code, c->d_chunk_off,
+              d_total_bits ? d_total_bits : c->d_u64, c->stream);
+  GHF_HIP(c, hipGetLastError());
+  c->plan_in = d_in;
+  c->plan_n = n;
+  c->plan_code = d_code;
+  return GHF_OK;
+}
+
+int ghf_encode_emit(ghf_ctx* c, const uint8_t* d_in, size_t n, const ghf_code* d_code, const uint64_t* d_start_bit,
+                    int flags, uint8_t* d_out, size_t cap, const ghf_index* index, uint64_t* d_end) {
+  if (!c || !d_code || !d_out || (n && !d_in)) return GHF_E_INVAL;
+  if (!aligned16(d_out)) return fail(c, GHF_E_INVAL, "d_out must be 16-byte aligned");
+  if (c->plan_in != d_in || c->plan_n != n || c->plan_code != d_code)
+    return fail(c, GHF_E_INVAL, "ghf_encode_emit: call ghf_encode_plan on the same (d_in, n, d_code) first");
+  GHF_HIP(c, hipSetDevice(c->device));
+  const uint32_t cl = chunk_log2_for(n);
+  const size_t nchunks = (n + ((size_t)1 << cl) - 1) >> cl;
+  if (index) {
+    if (index->n_symbols != n || index->chunk_symbols != (1u << cl) || index->seg_symbols != (uint32_t)kSegSymbols ||
+        !index->d_chunk_bit || !index->d_seg_bit)
+      return fail(c, GHF_E_INVAL, "ghf_encode_emit: index does not match n (use ghf_index_alloc)");
+  }
+  EmitParams p;
+  p.in = d_in;
+  p.n = n;
+  p.code = d_code;
+  p.chunk_off = c->d_chunk_off;
+  p.d_start_bit = d_start_bit;
+  p.out = d_out;
+  p.cap = cap;
+  p.chunk_log2 = cl;
+  p.nchunks = (uint32_t)nchunks;
+  p.chunk_bit = index ? index->d_chunk_bit : nullptr;
+  p.seg_bit = index ? index->d_seg_bit : nullptr;
+  p.flags = flags;
+  p.status = c->d_status;
+  p.d_end = d_end;
+  launch_emit(p, c->stream);
+  GHF_HIP(c, hipGetLastError());
+  return GHF_OK;
+}
+
+int ghf_compress(ghf_ctx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes,
+                 ghf_code* d_code, const ghf_index* index) {
+  if (!c || !d_out || (n && !d_in)) return GHF_E_INVAL;
+  if (n == 0) return fail(c, GHF_E_EMPTY, "empty input is undefined in the reference; refused");
+  if (!aligned16(d_out)) return fail(c, GHF_E_INVAL, "d_out must be 16-byte aligned");
+  ghf_code* code = d_code ? d_code : c->d_code;
+  int rc;
+  if ((rc = ghf_histogram(c, d_in, n, c->d_hist))) return rc;   // compressor.h:63
+  if ((rc = ghf_build_code(c, c->d_hist, code))) return rc;     // compressor.h:64
+  if ((rc = ghf_write_header(c, code, d_out, cap))) return rc;  // compressor.h:70
+  if ((rc = ghf_encode_plan(c, d_in, n, code, c->d_u64))) return rc;
+  if ((rc = ghf_encode_emit(c, d_in, n, code, nullptr, GHF_EMIT_LAST, d_out, cap, index, c->d_u64 + 1))) return rc;  // :72
+  if (d_out_bytes) {
+    launch_store_u64(d_out_bytes, c->d_u64 + 2, 0, c->stream);
+    GHF_HIP(c, hipGetLastError());
+  }
+  return GHF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- index
+int ghf_index_alloc(ghf_ctx* c, size_t n_symbols, ghf_index* out) {
+  if (!c || !out) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  std::memset(out, 0, sizeof *out);
+  const uint32_t cl = chunk_log2_for(n_symbols);
+  out->n_symbols = n_symbols;
+  out->chunk_symbols = 1u << cl;
+  out->seg_symbols = kSegSymbols;
+  out->n_chunks = (n_symbols + ((size_t)1 << cl) - 1) >> cl;
+  out->n_segs = (n_symbols + kSegSymbols - 1) / kSegSymbols;
+  GHF_HIP(c, hipMalloc(&out->d_chunk_bit, std::max<size_t>(out->n_chunks, 1) * sizeof(uint64_t)));
+  hipError_t e = hipMalloc(&out->d_seg_bit, std::max<size_t>(out->n_segs, 1) * sizeof(uint32_t));
+  if (e != hipSuccess) {
+    (void)hipFree(out->d_chunk_bit);
+    out->d_chunk_bit = nullptr;
+    return fail(c, GHF_E_HIP, "hipMalloc(seg_bit)", e);
+  }
+  return GHF_OK;
+}
+
+int ghf_index_free(ghf_ctx* c, ghf_index* idx) {
+  if (!c || !idx) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  GHF_HIP(c, hipStreamSynchronize(c->stream));
+  if (idx->d_chunk_bit) (void)hipFree(idx->d_chunk_bit);
+  if (idx->d_seg_bit) (void)hipFree(idx->d_seg_bit);
+  idx->d_chunk_bit = nullptr;
+  idx->d_seg_bit = nullptr;
+  return GHF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- decode
+static inline uint32_t be32(const uint8_t* p) {
+  return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+
+// canonical_huff_encoder.cc:349-374, plus the validation the reference does not do.
+int ghf_parse_header(const uint8_t* h, size_t n, ghf_code* code, size_t* header_bytes) {
+  if (!h || !code) return GHF_E_INVAL;
+  if (n < 1040) return GHF_E_FORMAT;
+  if (be32(h) != GHF_NSYM) return GHF_E_FORMAT;
+  std::memset(code, 0, sizeof *code);
+  const uint8_t* p = h + 4;
+  for (int i = 0; i < GHF_NSYM; ++i, p += 4) code->symbol[i] = be32(p);
+  const uint32_t min_len = be32(p), max_len = be32(p + 4);
+  p += 8;
+  if (max_len < 1 || max_len > 32 || min_len < 1 || min_len > max_len) return GHF_E_FORMAT;
+  if (n < 1040 + 8 * (size_t)max_len) return GHF_E_FORMAT;
+  code->min_len = (int32_t)min_len;
+  code->max_len = (int32_t)max_len;
+  for (uint32_t i = 1; i <= max_len; ++i, p += 8) {
+    code->start_pos[i] = be32(p);
+    code->first_code[i] = be32(p + 4);
+  }
+  // used symbols are a prefix of symbol_[], all distinct, the end mark among them
+  uint32_t used = 0;
+  while (used < GHF_NSYM && code->symbol[used] != 0xFFFFFFFFu) ++used;
+  bool seen[GHF_NSYM] = {false};
+  for (uint32_t i = 0; i < GHF_NSYM; ++i) {
+    const uint32_t s = code->symbol[i];
+    if (i < used) {
+      if (s >= GHF_NSYM || seen[s]) return GHF_E_FORMAT;
+      seen[s] = true;
+    } else if (s != 0xFFFFFFFFu) {
+      return GHF_E_FORMAT;
+    }
+  }
+  if (used < 2 || !seen[GHF_NSYM - 1]) return GHF_E_FORMAT;
+  // rebuild per-symbol lengths/codewords; the code must be the canonical complete prefix code
+  uint64_t kraft = 0;  // in units of 2^-32
+  for (uint32_t len = min_len; len <= max_len; ++len) {
+    const uint32_t a = code->start_pos[len];
+    const uint32_t b = (len < max_len) ? code->start_pos[len + 1] : used;
+    if (a > b || b > used) return GHF_E_FORMAT;
+    if (len == min_len && a != 0) return GHF_E_FORMAT;
+    const uint64_t fc = code->first_code[len];
+    if (fc + (b - a) > (1ull << len)) return GHF_E_FORMAT;
+    for (uint32_t r = 0; r < b - a; ++r) {
+      const uint32_t s = code->symbol[a + r];
+      code->length[s] = len;
+      code->codeword[s] = (uint32_t)fc + r;
+    }
+    kraft += (uint64_t)(b - a) << (32 - len);
+    if (len < max_len) {
+      // canonical_huff_encoder.cc:109-114: first_code[l] = (first_code[l+1] + num[l+1]) / 2
+      const uint32_t nb = ((len + 1 < max_len) ? code->start_pos[len + 2] : used) - code->start_pos[len + 1];
+      if (fc != ((uint64_t)code->first_code[len + 1] + nb) / 2) return GHF_E_FORMAT;
+    } else if (fc != 0) {
+      return GHF_E_FORMAT;
+    }
+  }
+  for (uint32_t i = 1; i < min_len; ++i)
+    if (code->first_code[i] != 1024) return GHF_E_FORMAT;  // canonical_huff_encoder.cc:119-121
+  if (kraft != (1ull << 32)) return GHF_E_FORMAT;
+  if (header_bytes) *header_bytes = 1040 + 8 * (size_t)max_len;
+  return GHF_OK;
+}
+
+int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, uint64_t origin_byte, const ghf_code* d_code,
+               const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes) {
+  if (!c || !d_stream || !d_code || !d_out) return GHF_E_INVAL;
+  if (!aligned16(d_stream) || (origin_byte & 15u)) return fail(c, GHF_E_INVAL, "d_stream/origin_byte must be 16-byte aligned");
+  if (!index) return fail(c, GHF_E_INVAL, "ghf_decode: decode without a side-car index is not implemented yet");
+  if (!index->d_chunk_bit || !index->d_seg_bit || index->seg_symbols != (uint32_t)kSegSymbols ||
+      (index->chunk_symbols & (index->chunk_symbols - 1)) || index->chunk_symbols < (uint32_t)kSegSymbols)
+    return fail(c, GHF_E_INVAL, "ghf_decode: malformed index");
+  if (cap < index->n_symbols) return fail(c, GHF_E_CAP, "ghf_decode: output capacity below n_symbols");
+  GHF_HIP(c, hipSetDevice(c->device));
+  launch_build_decode_tables(d_code, c->d_dt, c->d_status, c->stream);
+  DecParams p;
+  p.stream = d_stream;
+  p.stream_bytes = stream_bytes;
+  p.origin_byte = origin_byte;
+  p.dt = c->d_dt;
+  p.chunk_bit = index->d_chunk_bit;
+  p.seg_bit = index->d_seg_bit;
+  p.n_symbols = index->n_symbols;
+  p.n_segs = index->n_segs;
+  uint32_t cl = 0;
+  while ((1u << cl) < index->chunk_symbols) ++cl;
+  p.chunk_log2 = cl;
+  p.out = d_out;
+  p.status = c->d_status;
+  launch_decode(p, c->stream);
+  if (d_out_bytes) launch_store_u64(d_out_bytes, nullptr, index->n_symbols, c->stream);
+  GHF_HIP(c, hipGetLastError());
+  return GHF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// golden-huffman_amd/csrc/ghf_internal.h -- shared between the HIP kernels and the C-ABI host layer.
+#ifndef GHF_INTERNAL_H_
+#define GHF_INTERNAL_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ghf.h"
+
+namespace ghf {
+
+// ---- geometry ---------------------------------------------------------------------------------
+constexpr int kWave = 64;               // CDNA wavefront
+constexpr int kSymPerLane = 16;         // one 16-byte vector load = one lane's contiguous symbols
+constexpr int kSymPerIter = kWave * kSymPerLane;  // 1 KiB of input per wave iteration
+constexpr int kSegSymbols = 64;         // side-car granularity (4 lanes)
+constexpr uint32_t kMinChunkLog2 = 12;  // 4 KiB
+constexpr uint32_t kMaxChunkLog2 = 20;  // 1 MiB
+constexpr uint32_t kTargetChunks = 8192;
+
+// K1 histogram
+constexpr int kHistThreads = 256;
+constexpr int kHistRep = 32;  // bins[256][32]: replica = lane % 32 -> every lane of a 32-lane LDS group owns a bank
+
+// K5 emit
+constexpr int kEmitThreads = 512;                 // 8 waves share one 32 KiB replicated code table
+constexpr int kEmitWaves = kEmitThreads / kWave;
+constexpr int kStageWords = 544;                  // per-wave staging: 128 carry bits + 16384 bits + slack
+constexpr int kStageCapBits = (kStageWords - 8) * 32;
+
+// K7 decode
+constexpr int kDecThreads = 256;
+constexpr int kDecWaves = kDecThreads / kWave;
+constexpr int kDecLutBitsMax = 12;
+constexpr int kDecInBytes = 6016;                 // staged compressed span per wave (4096 symbols at <= 11.7 bits)
+constexpr int kDecInWords = kDecInBytes / 4;
+constexpr int kDecRowBytes = 80;                  // 64 output bytes per lane, padded
+constexpr int kDecOutBytes = kWave * kDecRowBytes;
+
+inline uint32_t chunk_log2_for(uint64_t n) {
+  uint32_t l = kMinChunkLog2;
+  while (l < kMaxChunkLog2 && ((n + ((1ull << l) - 1)) >> l) > kTargetChunks) ++l;
+  return l;
+}
+
+// decode-side tables derived from ghf_code (built on the device by k_build_decode_tables)
+struct DecTables {
+  uint32_t fc_left[36];    // first_code[len] << (32 - len), len = 1..max_len; 0xFFFFFFFF for len < min_len
+  uint32_t start_pos[36];
+  uint16_t symbol[GHF_NSYM + 3];
+  int32_t min_len, max_len, lut_bits, pad_;
+  uint16_t lut[1 << kDecLutBitsMax];  // sym | len << 9 ; 0 = code longer than lut_bits
+};
+
+struct EmitParams {
+  const uint8_t* in;
+  uint64_t n;
+  const ghf_code* code;
+  const uint64_t* chunk_off;  // [nchunks + 1] bits relative to this buffer's first code (exclusive scan)
+  const uint64_t* d_start_bit;
+  uint8_t* out;
+  uint64_t cap;
+  uint32_t chunk_log2;
+  uint32_t nchunks;
+  uint64_t* chunk_bit;  // side-car (may be null)
+  uint32_t* seg_bit;    // side-car (may be null)
+  int flags;
+  int* status;
+  uint64_t* d_end;  // may be null
+};
+
+struct DecParams {
+  const uint8_t* stream;
+  uint64_t stream_bytes;
+  uint64_t origin_byte;
+  const DecTables* dt;
+  const uint64_t* chunk_bit;
+  const uint32_t* seg_bit;
+  uint64_t n_symbols;
+  uint64_t n_segs;
+  uint32_t chunk_log2;
+  uint8_t* out;
+  int* status;
+};
+
+// kernel launchers (ghf_kernels.hip); all asynchronous on `s`
+void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, uint32_t* d_chunk_hist,
+                      uint64_t* d_hist, hipStream_t s);
+void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, hipStream_t s);
+void launch_write_header(const ghf_code* d_code, uint8_t* d_out, uint64_t cap, int* d_status, hipStream_t s);
+void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, const uint32_t* d_chunk_hist,
+                 const ghf_code* d_code, uint64_t* d_chunk_off, uint64_t* d_total_bits, hipStream_t s);
+void launch_emit(const EmitParams& p, hipStream_t s);
+void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_status, hipStream_t s);
+void launch_decode(const DecParams& p, hipStream_t s);
+void launch_store_u64(uint64_t* d_dst, const uint64_t* d_src_opt, uint64_t add, hipStream_t s);
+
+}  // namespace ghf
+#endif

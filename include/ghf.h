@@ -1,0 +1,153 @@
+/* include/ghf.h -- C ABI of libghf.so: the MI355X (gfx950) canonical-Huffman hot path.
+ *
+ * Drop-in boundary for the byte-keyed canonical-Huffman path of chenghuige/golden-huffman (`glzip`).
+ * Each entry point names the reference interface it replaces (file:line relative to the reference
+ * tree).  Plain pointers and sizes only; no C++/torch/HIP types cross this boundary (a HIP stream is
+ * passed as void*).  Every pointer whose name starts with d_ is DEVICE memory on the context's GPU
+ * and must be 16-byte aligned unless stated otherwise; everything else is host memory.
+ *
+ * All stage calls are asynchronous on the context's stream and never synchronise with the host.
+ * Device-side failures (code longer than 32 bits, empty input, output capacity exceeded) are latched
+ * in a device status word; ghf_sync() / ghf_status() return them.  No call throws.
+ *
+ * The product path has no CPU fallback: without a HIP device every stage call returns GHF_E_HIP.
+ */
+#ifndef GHF_H_
+#define GHF_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GHF_NSYM 257 /* include/type_traits.h:50 CharSymbolNum = 256 byte values + end-of-stream mark */
+
+enum ghf_status_code {
+  GHF_OK = 0,
+  GHF_E_INVAL = 1,   /* bad argument (null, misaligned, ...) */
+  GHF_E_HIP = 2,     /* HIP runtime error / no device; see ghf_last_error() */
+  GHF_E_EMPTY = 3,   /* n == 0: the reference is undefined there; we refuse */
+  GHF_E_CODELEN = 4, /* a code longer than 32 bits (reference limit, include/canonical_huff_encoder.h:43-44) */
+  GHF_E_CAP = 5,     /* output capacity too small */
+  GHF_E_FORMAT = 6,  /* not a .crs2 header */
+  GHF_E_CORRUPT = 7, /* stream does not decode to the expected symbol count / end mark */
+  GHF_E_NOMEM = 8
+};
+
+/* The encoder's tables -- mirrors the private members of CanonicalHuffEncoder,
+ * include/canonical_huff_encoder.h:107-120 (length_, codeword_, symbol_, first_code_, start_pos_,
+ * min_len_, max_len_).  first_code/start_pos are indexed from 1 like the reference's. */
+typedef struct ghf_code {
+  uint32_t length[GHF_NSYM];
+  uint32_t codeword[GHF_NSYM];
+  uint32_t symbol[GHF_NSYM]; /* unused tail = 0xFFFFFFFF (canonical_huff_encoder.cc:88) */
+  uint32_t first_code[64];   /* 1024 for len < min_len (canonical_huff_encoder.cc:119-121) */
+  uint32_t start_pos[64];
+  int32_t min_len;
+  int32_t max_len;
+} ghf_code;
+
+/* Side-car index for block-parallel decode (no reference counterpart: the .crs2 wire format has no
+ * sync points).  It is NOT part of the .crs2 bytes.  The struct lives on the host;
+ * the two arrays are device memory (ghf_index_alloc). */
+typedef struct ghf_index {
+  uint64_t n_symbols;     /* input bytes covered */
+  uint32_t chunk_symbols; /* symbols per chunk (power of two) */
+  uint32_t seg_symbols;   /* symbols per segment (64) */
+  uint64_t n_chunks;
+  uint64_t n_segs;
+  uint64_t* d_chunk_bit; /* [n_chunks] absolute stream bit (header included) of each chunk's first code */
+  uint32_t* d_seg_bit;   /* [n_segs]   bit offset of each segment relative to its chunk's first code */
+} ghf_index;
+
+typedef struct ghf_ctx ghf_ctx;
+
+/* ---- context (the reference has none: single-threaded objects; SURVEY 8b "Threading") ---------- */
+int ghf_ctx_create(int device, ghf_ctx** out);
+int ghf_ctx_destroy(ghf_ctx* ctx);
+int ghf_ctx_set_stream(ghf_ctx* ctx, void* hip_stream); /* NULL = the context's own stream */
+int ghf_sync(ghf_ctx* ctx);                             /* wait for the stream; returns latched device status */
+int ghf_status(ghf_ctx* ctx);                           /* = ghf_sync */
+int ghf_clear_status(ghf_ctx* ctx);
+const char* ghf_last_error(ghf_ctx* ctx);
+const char* ghf_status_string(int status);
+int ghf_version(void);
+
+/* ---- memory helpers, so that C/C++ hosts need no HIP headers.  They replace the 64 KiB stdio
+ *      buffers of utils/include/buffer.h:61-317 with pinned-host + hipMemcpyAsync staging. ------- */
+int ghf_device_alloc(ghf_ctx* ctx, size_t bytes, void** d_ptr);
+int ghf_device_free(ghf_ctx* ctx, void* d_ptr);
+int ghf_host_alloc(ghf_ctx* ctx, size_t bytes, void** h_ptr); /* pinned */
+int ghf_host_free(ghf_ctx* ctx, void* h_ptr);
+int ghf_copy_h2d(ghf_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* async on the stream */
+int ghf_copy_d2h(ghf_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* async on the stream */
+int ghf_memset_d(ghf_ctx* ctx, void* d_dst, int value, size_t bytes);
+
+/* ---- K1: Encoder::do_init + do_caculate_frequency, include/encoder.h:123-129,136-150 ------------
+ * d_hist[0..255] = byte counts of d_in[0..n), d_hist[256] = 1.  d_in needs no alignment (16-byte
+ * aligned input takes the fast path).  Also leaves per-chunk histograms in the context so that a
+ * following ghf_encode_plan on the same (d_in, n) does not re-read the input. */
+int ghf_histogram(ghf_ctx* ctx, const uint8_t* d_in, size_t n, uint64_t* d_hist);
+
+/* ---- K2+K3: CanonicalHuffEncoder::gen_encode = get_encoding_length + do_gen_encode,
+ *      include/canonical_huff_encoder.cc:35-42,289-345,69-141 -- on ONE wavefront, emulating
+ *      libstdc++'s priority_queue order exactly.  d_hist is not modified. */
+int ghf_build_code(ghf_ctx* ctx, const uint64_t* d_hist, ghf_code* d_code);
+
+/* ---- a5: CanonicalHuffEncoder::write_encode_info, include/canonical_huff_encoder.cc:210-242 ------
+ * Writes the 1040 + 8*max_len header bytes (big-endian u32, utils/include/buffer.h:255-268) at d_out. */
+int ghf_write_header(ghf_ctx* ctx, const ghf_code* d_code, uint8_t* d_out, size_t cap);
+size_t ghf_header_bytes(int max_len); /* 1040 + 8*max_len */
+
+/* ---- K4 + K5: CanonicalHuffEncoder::encode_file / encode_each_byte,
+ *      include/canonical_huff_encoder.cc:245-285 + Buffer::write_bits/write_bit/flush_bits,
+ *      utils/include/buffer.h:241-248,277-280,290-295 -- as a two-pass scheme.
+ * plan: per-chunk bit totals + exclusive scan; *d_total_bits = sum of code lengths of d_in[0..n)
+ *       (the end mark is not included).
+ * emit: every wave packs one chunk MSB-first into the pre-sized output.
+ *   d_start_bit : absolute stream bit of this buffer's first code (device u64); NULL = right after the
+ *                 header, i.e. 8*(1040+8*max_len)  (single-GPU case).
+ *   flags       : GHF_EMIT_LAST   append the end mark (symbol 256) and pad with 1-bits to a byte,
+ *                 GHF_EMIT_REBASE d_out[0] is stream byte 16*(start_bit/128) instead of stream byte 0
+ *                                 (shard-local output buffers of the multi-GPU path).
+ *   d_index     : optional side-car for ghf_decode (NULL = none).
+ *   d_end       : optional device u64[2] = { absolute end bit of what this call wrote (after padding),
+ *                 number of bytes of d_out that are now defined }.
+ * Both must be called with the same (d_in, n, d_code); plan first. */
+#define GHF_EMIT_LAST 1
+#define GHF_EMIT_REBASE 2
+int ghf_encode_plan(ghf_ctx* ctx, const uint8_t* d_in, size_t n, const ghf_code* d_code, uint64_t* d_total_bits);
+int ghf_encode_emit(ghf_ctx* ctx, const uint8_t* d_in, size_t n, const ghf_code* d_code, const uint64_t* d_start_bit,
+                    int flags, uint8_t* d_out, size_t cap, const ghf_index* index, uint64_t* d_end);
+
+/* ---- Compressor<CanonicalHuffEncoder<>>::compress(), include/compressor.h:62-73, in one call:
+ *      histogram -> code -> header -> plan -> emit, no host synchronisation in between.
+ *      d_out receives the complete .crs2 image; d_out_bytes (device u64) its size. */
+int ghf_compress(ghf_ctx* ctx, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes,
+                 ghf_code* d_code /* optional out */, const ghf_index* index /* optional */);
+size_t ghf_compress_bound(size_t n); /* capacity that always suffices (Huffman never beats 9 bits/symbol on 257 symbols) */
+
+/* ---- side-car index ------------------------------------------------------------------------------ */
+uint32_t ghf_chunk_symbols(size_t n); /* the chunk size the library uses for n input bytes */
+int ghf_index_alloc(ghf_ctx* ctx, size_t n_symbols, ghf_index* out);
+int ghf_index_free(ghf_ctx* ctx, ghf_index* idx);
+
+/* ---- a7: CanonicalHuffDecoder::get_encode_info, include/canonical_huff_encoder.cc:349-374 (host) -
+ * Parses and validates a .crs2 header (the reference trusts it blindly). code->length/codeword are
+ * reconstructed from symbol/start_pos/first_code. */
+int ghf_parse_header(const uint8_t* h_stream, size_t n, ghf_code* code, size_t* header_bytes);
+
+/* ---- K6/K7: decode_file of CanonicalHuffDecoder / FastCanonicalHuffDecoder /
+ *      TableCanonicalHuffDecoder, include/canonical_huff_encoder.cc:377-419,422-461,466-568 ---------
+ * d_stream[0] is stream byte `origin_byte` (0 for a whole .crs2 image).  With an index the decode is
+ * block-parallel (length-indexed canonical table in LDS); without one (index == NULL, a .crs2 written
+ * by the reference) the index is first rebuilt on the GPU from the bit stream.
+ * d_out_bytes: device u64 = decoded size. */
+int ghf_decode(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, uint64_t origin_byte, const ghf_code* d_code,
+               const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GHF_H_ */

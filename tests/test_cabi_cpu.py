@@ -1,0 +1,84 @@
+"""CPU (-m "not gpu"): the C-ABI library loads, exports every symbol include/ghf.h declares, its
+host-only entry points behave, and it refuses to work without a GPU (no CPU fallback in the product)."""
+import base64
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pkgload
+from cases import CASES
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def ghf():
+    pkg = pkgload.load()
+    if not os.path.exists(pkg.ghf.LIB_PATH):
+        pkg.build()
+    return pkg.ghf
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ghf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ghf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported(ghf):
+    L = ghf.lib()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "libghf.so does not export %s" % n
+    assert sorted(ghf.EXPORTS) == names
+
+
+def test_struct_layout_matches_header(ghf):
+    assert C.sizeof(ghf.Code) == 4 * (3 * 257 + 2 * 64 + 2)
+    assert C.sizeof(ghf.Index) == 48
+
+
+def test_no_cpu_fallback_without_gpu(ghf):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert ghf.lib().ghf_ctx_create(0, C.byref(h)) == 2  # GHF_E_HIP
+    assert not h.value
+
+
+def test_bounds_and_chunking(ghf):
+    for n in (1, 7, 4096, 65537, 1 << 20, 1 << 28, 1 << 32):
+        b = ghf.compress_bound(n)
+        assert b % 16 == 0 and b >= 1040 + 256 + (9 * (n + 1) + 7) // 8
+        c = ghf.chunk_symbols(n)
+        assert c & (c - 1) == 0 and 4096 <= c <= (1 << 20)
+        assert -(-n // c) <= 8192 or c == (1 << 20)
+    assert ghf.lib().ghf_header_bytes(9) == 1112
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_parse_header_against_reference_headers(ghf, golden, name):
+    g = golden[name]
+    hdr = np.frombuffer(base64.b64decode(g["header_b64"]), dtype=np.uint8)
+    code, hs = ghf.parse_header(hdr)
+    assert hs == g["header_bytes"]
+    d = code.as_dict()
+    for k in ("symbol", "first_code", "start_pos", "min_len", "max_len", "length", "codeword"):
+        assert d[k] == g[k], k
+
+
+def test_parse_header_rejects_garbage(ghf, golden):
+    hdr = np.frombuffer(base64.b64decode(golden["zipf_64k"]["header_b64"]), dtype=np.uint8).copy()
+    for pos, val in ((3, 0), (1035, 99), (1039, 40), (8, 7), (1047, 5)):
+        bad = hdr.copy()
+        bad[pos] = val
+        with pytest.raises(ghf.GhfError):
+            ghf.parse_header(bad)
+    with pytest.raises(ghf.GhfError):
+        ghf.parse_header(hdr[:500])

@@ -1,0 +1,212 @@
+"""GPU (-m gpu): the HIP path through the C ABI against the oracle and the committed golden vectors.
+Bit-exact everywhere (integer/byte work: no tolerance)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import datagen as dg
+import pkgload
+from cases import CASES
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    pkg = pkgload.load()
+    ctx = pkg.ghf.Context(0)
+    yield pkg.ghf, ctx, torch
+    ctx.close()
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_compress(ghf, ctx, torch, data, with_index=True):
+    d_in = to_dev(torch, data)
+    idx = ctx.index_alloc(data.size) if with_index else None
+    d_out, nbytes, d_code = ctx.compress(d_in, index=idx)
+    ctx.sync()
+    nb = int(nbytes.item())
+    return d_in, d_out, nb, d_code, idx
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_every_stage_matches_reference_fixture(env, golden, name):
+    ghf, ctx, torch = env
+    g = golden[name]
+    data = CASES[name]()
+    assert sha(data) == g["input_sha256"]
+    d_in = to_dev(torch, data)
+    # K1
+    hist = ctx.histogram(d_in)
+    ctx.sync()
+    assert hist.cpu().numpy().tolist() == g["hist"]
+    # K2 + K3
+    d_code = ctx.build_code(hist)
+    ctx.sync()
+    d = ctx.code_to_host(d_code).as_dict()
+    for k in ("length", "codeword", "symbol", "first_code", "start_pos", "min_len", "max_len"):
+        assert d[k] == g[k], k
+    # whole pipeline
+    _, d_out, nb, d_code2, idx = run_compress(ghf, ctx, torch, data)
+    crs = d_out[:nb].cpu().numpy()
+    assert nb == g["crs2_bytes"]
+    assert sha(crs[: g["header_bytes"]]) == sha(orc.header_bytes(orc.build_code(orc.histogram(data))))
+    assert sha(crs) == g["crs2_sha256"], "first diff at %s" % first_diff(crs, orc.compress(data))
+    # K7 with the side-car
+    back, nout = ctx.decode(d_out, nb, d_code2, idx)
+    ctx.sync()
+    assert int(nout.item()) == data.size
+    assert np.array_equal(back[: data.size].cpu().numpy(), data)
+    ctx.index_free(idx)
+
+
+def first_diff(a, b):
+    n = min(a.size, b.size)
+    d = np.nonzero(a[:n] != b[:n])[0]
+    return (int(d[0]) if d.size else None, a.size, b.size)
+
+
+@pytest.mark.parametrize("kind,n", [("uniform", (1 << 24) + 5), ("zipf", (1 << 24) - 3), ("sym16", 1 << 24), ("text", 3 << 20)])
+def test_mid_size_bit_exact_vs_oracle(env, kind, n):
+    ghf, ctx, torch = env
+    data = dg.make(kind, n, seed=99)
+    _, d_out, nb, d_code, idx = run_compress(ghf, ctx, torch, data)
+    ref = orc.compress(data)
+    crs = d_out[:nb].cpu().numpy()
+    assert nb == ref.size and np.array_equal(crs, ref), first_diff(crs, ref)
+    back, _ = ctx.decode(d_out, nb, d_code, idx)
+    ctx.sync()
+    assert np.array_equal(back[:n].cpu().numpy(), data)
+    ctx.index_free(idx)
+
+
+def test_unaligned_input_pointer(env):
+    ghf, ctx, torch = env
+    data = dg.zipf_bytes(200001, seed=5)
+    big = to_dev(torch, np.concatenate([np.zeros(3, np.uint8), data]))
+    d_in = big[3:]
+    assert d_in.data_ptr() % 16 == 3
+    idx = ctx.index_alloc(data.size)
+    d_out, nbytes, d_code = ctx.compress(d_in, index=idx)
+    ctx.sync()
+    nb = int(nbytes.item())
+    assert np.array_equal(d_out[:nb].cpu().numpy(), orc.compress(data))
+    ctx.index_free(idx)
+
+
+def test_plan_without_histogram_uses_direct_pass(env):
+    """ghf_encode_plan must not depend on a preceding ghf_histogram of the same buffer."""
+    ghf, ctx, torch = env
+    data = dg.text_bytes(300000, seed=8)
+    other = dg.uniform_bytes(300000, seed=9)
+    d_in, d_other = to_dev(torch, data), to_dev(torch, other)
+    hist = ctx.histogram(d_in)
+    d_code = ctx.build_code(hist)
+    ctx.histogram(d_other)  # invalidates the cached per-chunk histograms
+    out = ctx.empty_u8(ghf.compress_bound(data.size))
+    ctx.write_header(d_code, out)
+    total = ctx.encode_plan(d_in, d_code)
+    end = ctx.encode_emit(d_in, d_code, out)
+    ctx.sync()
+    ref = orc.compress(data)
+    assert int(end[1].item()) == ref.size
+    assert np.array_equal(out[: ref.size].cpu().numpy(), ref)
+    h = orc.histogram(data)
+    assert int(total.item()) == orc.body_bits(h, orc.build_code(h)) - orc.build_code(h).length[256]
+
+
+def test_error_statuses(env):
+    ghf, ctx, torch = env
+    # empty input: refused (the reference is undefined there)
+    with pytest.raises(ghf.GhfError) as e:
+        ctx.compress(ctx.empty_u8(16), n=0)
+    assert e.value.status == 3
+    # 33-bit codes: refused (reference limit)
+    h = np.zeros(257, dtype=np.int64)
+    h[:33] = dg.fib_counts(33)
+    h[256] = 1
+    ctx.build_code(to_dev(torch, h))
+    with pytest.raises(ghf.GhfError) as e:
+        ctx.sync()
+    assert e.value.status == 4
+    # capacity
+    data = dg.uniform_bytes(100000, seed=3)
+    small = ctx.empty_u8(50000)
+    ctx.compress(to_dev(torch, data), d_out=small)
+    with pytest.raises(ghf.GhfError) as e:
+        ctx.sync()
+    assert e.value.status == 5
+    # and the context still works afterwards
+    d_out, nbytes, _ = ctx.compress(to_dev(torch, data))
+    ctx.sync()
+    assert np.array_equal(d_out[: int(nbytes.item())].cpu().numpy(), orc.compress(data))
+
+
+def test_decode_detects_corruption(env):
+    ghf, ctx, torch = env
+    data = dg.zipf_bytes(500000, seed=17)
+    _, d_out, nb, d_code, idx = run_compress(ghf, ctx, torch, data)
+    bad = d_out.clone()
+    bad[2000:2064] ^= 0x5A
+    ctx.decode(bad, nb, d_code, idx)
+    with pytest.raises(ghf.GhfError) as e:
+        ctx.sync()
+    assert e.value.status == 7
+    ctx.index_free(idx)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf", "sym16"])
+def test_full_size_256MiB_properties(env, kind):
+    """BASELINE config 2 size: properties that do not need the (slow) CPU oracle on the whole buffer:
+    exact histogram, tables == oracle(tables from that histogram), size == sum(freq*len), exact round trip,
+    1-padding, and an oracle-exact check of the first and last 1 MiB worth of the body."""
+    ghf, ctx, torch = env
+    n = 1 << 28
+    data = dg.make(kind, n, seed=2024)
+    d_in = to_dev(torch, data)
+    idx = ctx.index_alloc(n)
+    d_out, nbytes, d_code = ctx.compress(d_in, index=idx)
+    ctx.sync()
+    nb = int(nbytes.item())
+    hist = np.bincount(data, minlength=256).astype(np.int64)
+    hist = np.concatenate([hist, [1]])
+    assert ctx.histogram(d_in).cpu().numpy().tolist() == hist.tolist()
+    ocode = orc.build_code(hist)
+    gcode = ctx.code_to_host(d_code)
+    assert gcode.as_dict() == ocode.as_dict()
+    hs = 1040 + 8 * ocode.max_len
+    bits = orc.body_bits(hist, ocode)
+    assert nb == hs + (bits + 7) // 8
+    head = d_out[: hs + (1 << 20)].cpu().numpy()
+    assert np.array_equal(head[:hs], orc.header_bytes(ocode))
+    # first MiB of body == oracle packing of a long enough prefix
+    pre = orc.compress(data[: 2 << 20])  # different code! so pack with the global code instead:
+    import ctypes as C
+    cap = 4 << 20
+    buf = np.zeros(cap, dtype=np.uint8)
+    m = 1 << 20
+    w = orc.lib().orc_encode_body(data.ctypes.data, m, C.byref(ocode), buf.ctypes.data, cap)
+    pbits = int(sum(int(ocode.length[b]) for b in data[:m]))
+    assert np.array_equal(head[hs : hs + pbits // 8], buf[: pbits // 8])
+    del pre, w
+    # round trip
+    back, _ = ctx.decode(d_out, nb, d_code, idx)
+    ctx.sync()
+    assert bool((back[:n] == d_in).all().item())
+    # padding bits are ones (buffer.h:277-280)
+    pad = (8 - bits % 8) % 8
+    last = int(d_out[nb - 1].item())
+    assert last & ((1 << pad) - 1) == (1 << pad) - 1
+    ctx.index_free(idx)
