@@ -37,6 +37,8 @@ struct ghf_ctx {
 
 namespace {
 
+thread_local std::string g_create_err;  // ghf_last_error(NULL): why ghf_ctx_create failed
+
 int fail(ghf_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
   if (c) {
     c->err = what;
@@ -103,21 +105,33 @@ int ghf_ctx_create(int device, ghf_ctx** out) {
   if (!out) return GHF_E_INVAL;
   *out = nullptr;
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GHF_E_HIP;  // no CPU fallback, by design
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {  // no CPU fallback, by design
+    g_create_err = std::string("hipGetDeviceCount: ") + (e != hipSuccess ? hipGetErrorString(e) : "no device");
+    return GHF_E_HIP;
+  }
   if (device < 0 || device >= ndev) return GHF_E_INVAL;
   ghf_ctx* c = new (std::nothrow) ghf_ctx();
   if (!c) return GHF_E_NOMEM;
   c->device = device;
-  hipError_t e = hipSetDevice(device);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipMalloc(&c->d_status, sizeof(int));
-  if (e == hipSuccess) e = hipHostMalloc(&c->h_status, sizeof(int), hipHostMallocDefault);
-  if (e == hipSuccess) e = hipMalloc(&c->d_hist, GHF_NSYM * sizeof(uint64_t));
-  if (e == hipSuccess) e = hipMalloc(&c->d_code, sizeof(ghf_code));
-  if (e == hipSuccess) e = hipMalloc(&c->d_dt, sizeof(DecTables));
-  if (e == hipSuccess) e = hipMalloc(&c->d_u64, 8 * sizeof(uint64_t));
-  if (e == hipSuccess) e = hipMemset(c->d_status, 0, sizeof(int));
+  const char* what = "hipSetDevice";
+  e = hipSetDevice(device);
+#define GHF_STEP(call)      \
+  if (e == hipSuccess) {    \
+    what = #call;           \
+    e = (call);             \
+  }
+  GHF_STEP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  GHF_STEP(hipMalloc(&c->d_status, sizeof(int)));
+  GHF_STEP(hipHostMalloc(&c->h_status, sizeof(int), hipHostMallocDefault));
+  GHF_STEP(hipMalloc(&c->d_hist, GHF_NSYM * sizeof(uint64_t)));
+  GHF_STEP(hipMalloc(&c->d_code, sizeof(ghf_code)));
+  GHF_STEP(hipMalloc(&c->d_dt, sizeof(DecTables)));
+  GHF_STEP(hipMalloc(&c->d_u64, 8 * sizeof(uint64_t)));
+  GHF_STEP(hipMemset(c->d_status, 0, sizeof(int)));
+#undef GHF_STEP
   if (e != hipSuccess) {
+    g_create_err = std::string(what) + ": " + hipGetErrorString(e);
     ghf_ctx_destroy(c);
     return GHF_E_HIP;
   }
@@ -169,7 +183,7 @@ int ghf_clear_status(ghf_ctx* c) {
   return GHF_OK;
 }
 
-const char* ghf_last_error(ghf_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* ghf_last_error(ghf_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 // ---------------------------------------------------------------------------------------------- memory
 int ghf_device_alloc(ghf_ctx* c, size_t bytes, void** d_ptr) {

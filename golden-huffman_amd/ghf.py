@@ -77,6 +77,13 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise GhfError(2, "load", "libghf.so not built: run `make -C golden-huffman_amd` (or __graft_entry__.build())")
+    # One HIP runtime per process: torch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  Import
+    # torch FIRST so that libghf.so's DT_NEEDED libamdhip64.so.7 binds to the copy torch already mapped; loading
+    # libghf.so first would map /opt/rocm's runtime beside torch's and the second one finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, u64, i32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
     L.ghf_ctx_create.argtypes = [i32, C.POINTER(vp)]
@@ -149,7 +156,7 @@ class Context:
         h = C.c_void_p()
         rc = self.L.ghf_ctx_create(device, C.byref(h))
         if rc:
-            raise GhfError(rc, "ghf_ctx_create")
+            raise GhfError(rc, "ghf_ctx_create", self.L.ghf_last_error(None).decode(errors="replace"))
         self.h = h
         self.use_current_stream()
 
