@@ -159,7 +159,7 @@ int ghf_ctx_destroy(ghf_ctx* c) {
 
 int ghf_ctx_set_stream(ghf_ctx* c, void* hip_stream) {
   if (!c) return GHF_E_INVAL;
-  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  c->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL is HIP's default (null) stream
   return GHF_OK;
 }
 

@@ -66,7 +66,9 @@ typedef struct ghf_ctx ghf_ctx;
 /* ---- context (the reference has none: single-threaded objects; SURVEY 8b "Threading") ---------- */
 int ghf_ctx_create(int device, ghf_ctx** out);
 int ghf_ctx_destroy(ghf_ctx* ctx);
-int ghf_ctx_set_stream(ghf_ctx* ctx, void* hip_stream); /* NULL = the context's own stream */
+/* A new context owns a private non-blocking stream.  ghf_ctx_set_stream makes it queue on the caller's
+ * hipStream_t instead (NULL = HIP's default stream), e.g. torch's current stream. */
+int ghf_ctx_set_stream(ghf_ctx* ctx, void* hip_stream);
 int ghf_sync(ghf_ctx* ctx);                             /* wait for the stream; returns latched device status */
 int ghf_status(ghf_ctx* ctx);                           /* = ghf_sync */
 int ghf_clear_status(ghf_ctx* ctx);
