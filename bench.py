@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- canonical-Huffman encode+decode throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic buffer per rank: histogram -> one-wave code
+build -> header -> bit-length scan -> bit-pack (encode), then table decode of the result.  The input is
+resident in HBM before the timed region.  N=1: BASELINE config 2 (256 MiB uniform-random bytes).
+N>1: every rank holds a 256 MiB shard of one N x 256 MiB stream (weak scaling); one global code via an
+RCCL all-reduce of the 256-bin histogram and an all-gather of the per-rank bit totals.
+
+Rank 0 prints ONE JSON line.  `value` = input GB (1e9 B) pushed through encode+decode per second by the
+whole job.  `roofline` prices the dominant kernel against HBM peak; `cpu_baseline` is the reference's
+own code (oracle/_ref, built from /root/reference in the build container) timed on this host, 1 core.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mib", type=int, default=256, help="input MiB per GPU")
+    ap.add_argument("--kind", default="uniform", choices=["uniform", "zipf", "sym16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(data_host, kind):
+    """the reference path on this host's CPU, 1 thread (the reference is single-threaded)."""
+    import numpy as np
+
+    from oracle import oracle as orc
+
+    n = data_host.size
+    cpu = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    if orc.have_ref():
+        d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        fin, fout, fde = (os.path.join(d, "ghf_bench_%d.%s" % (os.getpid(), e)) for e in ("bin", "crs2", "de"))
+        try:
+            data_host.tofile(fin)
+            t = json.loads(orc.ref_run(["b", fin, fout, fde], timeout=600))
+            ok = os.path.getsize(fde) == n
+        finally:
+            for f in (fin, fout, fde):
+                if os.path.exists(f):
+                    os.remove(f)
+        enc, dec = t["encode_total_s"], t["decode_bitserial_s"]
+        return {"value": n / (enc + dec) / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference",
+                "sample": "%d MiB %s (the whole N=1 workload), file-to-file in %s" % (n >> 20, kind, d),
+                "encode_GBps": n / enc / 1e9, "decode_GBps": n / dec / 1e9, "histogram_GBps": n / t["histogram_s"] / 1e9,
+                "round_trip_ok": bool(ok), "cpu": cpu, "host_cores": os.cpu_count()}
+    m = min(n, 64 << 20)
+    sample = np.ascontiguousarray(data_host[:m])
+    t0 = time.perf_counter()
+    crs = orc.compress(sample)
+    t1 = time.perf_counter()
+    back = orc.decompress(crs, cap=m + 8)
+    t2 = time.perf_counter()
+    return {"value": m / (t2 - t0) / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "first %d MiB of the N=1 workload, in memory" % (m >> 20), "encode_GBps": m / (t1 - t0) / 1e9,
+            "decode_GBps": m / (t2 - t1) / 1e9, "round_trip_ok": bool(np.array_equal(back, sample)), "cpu": cpu,
+            "host_cores": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import torch
+
+    import pkgload
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    pkg = pkgload.load()
+    ghf = pkg.ghf
+    from golden_huffman_amd import sharded, synth
+
+    ctx = ghf.Context(local_rank)
+    n = args.mib << 20
+    d_in = synth.make(torch, args.kind, n, offset=rank * n, device="cuda")
+    bound = ghf.compress_bound(n)
+    out = ctx.empty_u8(bound)
+    dec = ctx.empty_u8(n)
+    d_code = ctx.new_code()
+    index = ctx.index_alloc(n)
+    torch.cuda.synchronize()
+
+    names = ["histogram", "allreduce", "build_code", "header", "plan", "allgather", "emit", "decode"]
+    acc_ms = {k: 0.0 for k in names}
+    ev_steps = []
+
+    def step(record):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(9)] if record else None
+
+        def mark(i):
+            if ev is not None:
+                ev[i].record()
+
+        mark(0)
+        hist = ctx.histogram(d_in)
+        mark(1)
+        if world > 1:
+            dist.all_reduce(hist[:256], op=dist.ReduceOp.SUM)
+        mark(2)
+        ctx.build_code(hist, d_code)
+        mark(3)
+        if rank == 0:
+            ctx.write_header(d_code, out)
+        mark(4)
+        total = ctx.encode_plan(d_in, d_code)
+        mark(5)
+        if world > 1:
+            totals = torch.empty(world, dtype=torch.int64, device="cuda")
+            dist.all_gather_into_tensor(totals, total)
+            before = totals[:rank].sum().reshape(1)
+            start_bit = sharded.header_bits_of(ctx, d_code) + before
+            flags = (ghf.EMIT_LAST if rank == world - 1 else 0) | (ghf.EMIT_REBASE if rank > 0 else 0)
+        else:
+            start_bit, flags = None, ghf.EMIT_LAST
+        mark(6)
+        end = ctx.encode_emit(d_in, d_code, out, start_bit=start_bit, flags=flags, index=index)
+        mark(7)
+        ctx.decode(out, bound, d_code, index, d_out=dec)
+        mark(8)
+        if ev is not None:
+            ev_steps.append(ev)
+        return end
+
+    for _ in range(args.warmup):
+        end = step(False)
+    torch.cuda.synchronize()
+    ctx.sync()
+    if not args.no_verify:
+        assert bool((dec[:n] == d_in).all().item()), "round trip mismatch"
+    comp_bytes = int(end[1].item())
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.sync()  # raises if any stage latched an error
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    for ev in ev_steps:
+        for i, k in enumerate(names):
+            acc_ms[k] += ev[i].elapsed_time(ev[i + 1])
+    stage_ms = {k: v / max(len(ev_steps), 1) for k, v in acc_ms.items()}
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        total_in = n * world
+        value = total_in * args.steps / elapsed / 1e9
+        enc_ms = sum(stage_ms[k] for k in names[:7])
+        # roofline of the dominant kernel (algorithmic bytes): emit reads N and writes the body,
+        # decode reads C and writes N, histogram reads N
+        body_bytes = comp_bytes if world == 1 else comp_bytes  # per-rank bytes written by emit
+        cand = {"k_emit": (n + body_bytes, stage_ms["emit"]), "k_decode": (comp_bytes + n, stage_ms["decode"]),
+                "k_histogram": (n, stage_ms["histogram"])}
+        dom = max(cand, key=lambda k: cand[k][1])
+        ach = cand[dom][0] / (cand[dom][1] * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("%s_%s_%dMiB" % (dom, args.kind, args.mib))
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "encode+decode GB/s (input bytes)", "value": round(value, 3), "unit": "GB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%d MiB %s bytes per GPU, encode (.crs2 bit-exact with the reference) + decode" % (args.mib, args.kind),
+                       "baseline_config": "configs[1]" if (world == 1 and args.kind == "uniform" and args.mib == 256) else "configs[3]-style shard",
+                       "bytes_per_gpu": n, "compressed_bytes_per_gpu": comp_bytes, "parallelism": "shard%d" % world,
+                       "collectives": "none" if world == 1 else "all_reduce(256 x i64) + all_gather(1 x i64) per step"},
+            "encode_GBps": round(n * world / (enc_ms * 1e-3) / 1e9, 3), "decode_GBps": round(n * world / (stage_ms["decode"] * 1e-3) / 1e9, 3),
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": cand[dom][0], "avg_launch_ms": round(cand[dom][1], 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(d_in.cpu().numpy(), args.kind)
+        print(json.dumps(res), flush=True)
+    ctx.index_free(index)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -444,10 +444,10 @@ int ghf_parse_header(const uint8_t* h, size_t n, ghf_code* code, size_t* header_
   return GHF_OK;
 }
 
-int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, uint64_t origin_byte, const ghf_code* d_code,
+int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code,
                const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes) {
   if (!c || !d_stream || !d_code || !d_out) return GHF_E_INVAL;
-  if (!aligned16(d_stream) || (origin_byte & 15u)) return fail(c, GHF_E_INVAL, "d_stream/origin_byte must be 16-byte aligned");
+  if (!aligned16(d_stream)) return fail(c, GHF_E_INVAL, "d_stream must be 16-byte aligned");
   if (!index) return fail(c, GHF_E_INVAL, "ghf_decode: decode without a side-car index is not implemented yet");
   if (!index->d_chunk_bit || !index->d_seg_bit || index->seg_symbols != (uint32_t)kSegSymbols ||
       (index->chunk_symbols & (index->chunk_symbols - 1)) || index->chunk_symbols < (uint32_t)kSegSymbols)
@@ -458,7 +458,6 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, uint64_
   DecParams p;
   p.stream = d_stream;
   p.stream_bytes = stream_bytes;
-  p.origin_byte = origin_byte;
   p.dt = c->d_dt;
   p.chunk_bit = index->d_chunk_bit;
   p.seg_bit = index->d_seg_bit;

@@ -30,10 +30,8 @@ constexpr int kStageCapBits = (kStageWords - 8) * 32;
 constexpr int kDecThreads = 256;
 constexpr int kDecWaves = kDecThreads / kWave;
 constexpr int kDecLutBitsMax = 12;
-constexpr int kDecInBytes = 6016;                 // staged compressed span per wave (4096 symbols at <= 11.7 bits)
+constexpr int kDecInBytes = 5120;                 // staged compressed span per wave (4096 symbols at <= 10 bits average)
 constexpr int kDecInWords = kDecInBytes / 4;
-constexpr int kDecRowBytes = 80;                  // 64 output bytes per lane, padded
-constexpr int kDecOutBytes = kWave * kDecRowBytes;
 
 inline uint32_t chunk_log2_for(uint64_t n) {
   uint32_t l = kMinChunkLog2;
@@ -70,7 +68,6 @@ struct EmitParams {
 struct DecParams {
   const uint8_t* stream;
   uint64_t stream_bytes;
-  uint64_t origin_byte;
   const DecTables* dt;
   const uint64_t* chunk_bit;
   const uint32_t* seg_bit;

@@ -583,7 +583,7 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, cons
   W.carry = (uint32_t)(Pc & 127u);
   W.first_pending = true;
   if (lane < 8) st[lane] = 0;
-  if (lane == 0 && P.chunk_bit) P.chunk_bit[c] = Pc;
+  if (lane == 0 && P.chunk_bit) P.chunk_bit[c] = Pc - origin_byte * 8;  // relative to d_out[0]
   wave_sync();
   uint64_t relbits = 0;
   const uint64_t niter = (nsym + kSymPerIter - 1) / kSymPerIter;
@@ -789,7 +789,6 @@ void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_
 
 struct DecLds {
   alignas(16) uint32_t in[kDecWaves][kDecInWords + 4];
-  alignas(16) uint32_t out[kDecWaves][kDecOutBytes / 4];
   alignas(16) uint16_t lut[1 << kDecLutBitsMax];
   uint32_t fcl[36];
   uint32_t sp[36];
@@ -797,20 +796,110 @@ struct DecLds {
   int status0;
 };
 
-// one symbol from the left-justified 64-bit window
-__device__ __forceinline__ uint32_t dec_symbol(const DecLds& L, uint64_t window, int lut_bits, int max_len, uint32_t& len) {
-  const uint32_t hi = (uint32_t)(window >> 32);
-  const uint32_t ent = L.lut[hi >> (32 - lut_bits)];
-  len = ent >> 9;
-  if (len) return ent & 0x1FFu;
-  // canonical_huff_encoder.cc:554-557: extend linearly from the table's length
+// codes longer than the direct table: the reference's linear extension (canonical_huff_encoder.cc:554-557).
+// returns sym | len << 16
+__device__ __forceinline__ uint32_t dec_long(const DecLds& L, uint32_t hi, int lut_bits, int max_len) {
   int l = lut_bits + 1;
   while (l < max_len && hi < L.fcl[l]) ++l;
-  len = (uint32_t)l;
   const uint32_t k = L.sp[l] + ((hi - L.fcl[l]) >> (32 - l));
-  return k < GHF_NSYM ? L.symbol[k] : 256u;
+  return (k < GHF_NSYM ? (uint32_t)L.symbol[k] : 256u) | ((uint32_t)l << 16);
 }
 
+template <bool STAGED>
+struct DecIn {
+  const uint32_t* in;   // staged big-endian words
+  const uint8_t* src;   // unstaged: raw bytes of the span
+  uint64_t span;
+  __device__ __forceinline__ uint32_t fetch(uint32_t widx) const {
+    if (STAGED) return in[widx];
+    const uint64_t b = (uint64_t)widx * 4;
+    uint32_t r = 0;
+    for (int k = 0; k < 4; ++k) r = (r << 8) | (b + k < span ? (uint32_t)src[b + k] : 0u);
+    return r;
+  }
+};
+
+// decode this lane's segment (cnt symbols starting at bit `pos` of the span) and store the bytes.
+// returns 256-flagged garbage accumulator: bit 8 set <=> corrupt.
+template <bool STAGED>
+__device__ __forceinline__ uint32_t decode_segment(const DecLds& L, const DecIn<STAGED>& I, int lut_bits, int max_len,
+                                                   uint64_t pos, uint32_t cnt, bool valid, bool all_full, uint8_t* optr,
+                                                   bool has_next, uint64_t expect_bits) {
+  const int lsh = 32 - lut_bits;
+  uint32_t widx = (uint32_t)(pos >> 5);
+  const uint32_t off = (uint32_t)(pos & 31u);
+  uint64_t window = (((uint64_t)I.fetch(widx) << 32) | I.fetch(widx + 1)) << off;
+  uint32_t nextw = I.fetch(widx + 2);
+  widx += 3;
+  int avail = 64 - (int)off;
+  uint32_t used = 0, bad_acc = 0;
+
+#define GHF_DEC_ONE(SYM)                                 \
+  do {                                                   \
+    if (avail < 32) {                                    \
+      window |= (uint64_t)nextw << (32 - avail);         \
+      avail += 32;                                       \
+      nextw = I.fetch(widx++);                           \
+    }                                                    \
+    const uint32_t hi_ = (uint32_t)(window >> 32);       \
+    uint32_t ent_ = L.lut[hi_ >> lsh];                   \
+    uint32_t len_ = ent_ >> 9;                           \
+    SYM = ent_ & 0x1FFu;                                 \
+    if (__builtin_expect(len_ == 0, 0)) {                \
+      ent_ = dec_long(L, hi_, lut_bits, max_len);        \
+      len_ = ent_ >> 16;                                 \
+      SYM = ent_ & 0xFFFFu;                              \
+    }                                                    \
+    window <<= len_;                                     \
+    avail -= (int)len_;                                  \
+    used += len_;                                        \
+  } while (0)
+
+  if (all_full) {
+    // full segments everywhere (all groups but the stream's last): 16 output bytes per store
+    for (int q = 0; q < 4; ++q) {
+      uint32_t wq[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint32_t s0, s1, s2, s3;
+        GHF_DEC_ONE(s0);
+        GHF_DEC_ONE(s1);
+        GHF_DEC_ONE(s2);
+        GHF_DEC_ONE(s3);
+        bad_acc |= (s0 | s1 | s2 | s3);
+        wq[k] = (s0 & 0xFFu) | ((s1 & 0xFFu) << 8) | ((s2 & 0xFFu) << 16) | (s3 << 24);
+      }
+      if (valid) *reinterpret_cast<uint4*>(optr + q * 16) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+    }
+  } else if (valid) {
+    for (uint32_t i = 0; i < cnt; ++i) {
+      uint32_t sy;
+      GHF_DEC_ONE(sy);
+      bad_acc |= sy;
+      optr[i] = (uint8_t)sy;
+    }
+  }
+  if (valid) {
+    // the index says where the next segment starts: an end-to-end check of every segment
+    if (has_next) {
+      if ((uint64_t)used != expect_bits) bad_acc |= 256u;
+    } else {
+      uint32_t sy;
+      GHF_DEC_ONE(sy);
+      if (sy != 256u) bad_acc |= 256u;  // canonical_huff_encoder.cc:404: the end mark must follow
+      else bad_acc &= ~256u;
+    }
+  }
+#undef GHF_DEC_ONE
+  return bad_acc;
+}
+
+// K7.  Persistent waves; each pass a wave takes 64 consecutive segments (4096 symbols):
+//   1. the compressed span of those segments (known from the side-car) is copied into LDS with
+//      coalesced 16-byte loads, byte-swapped to big-endian words;
+//   2. every lane decodes its 64 symbols from a left-justified 64-bit window: one LDS table lookup
+//      per symbol, the next 32-bit word is prefetched one refill ahead;
+//   3. every 16 symbols the lane stores 16 output bytes straight to HBM (its 64 bytes are contiguous).
 __global__ __launch_bounds__(kDecThreads) void k_decode(DecParams P) {
   __shared__ DecLds L;
   const int tid = threadIdx.x;
@@ -818,7 +907,11 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(DecParams P) {
   __syncthreads();
   if (L.status0 != 0) return;
   const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
-  for (int i = tid; i < (1 << lut_bits); i += kDecThreads) L.lut[i] = P.dt->lut[i];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(P.dt->lut);
+    uint4* dst = reinterpret_cast<uint4*>(L.lut);
+    for (int i = tid; i < ((1 << lut_bits) * 2 + 15) / 16; i += kDecThreads) dst[i] = src[i];
+  }
   if (tid < 36) {
     L.fcl[tid] = P.dt->fc_left[tid];
     L.sp[tid] = P.dt->start_pos[tid];
@@ -826,130 +919,85 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(DecParams P) {
   for (int i = tid; i < GHF_NSYM; i += kDecThreads) L.symbol[i] = P.dt->symbol[i];
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
-  const uint64_t group = (uint64_t)blockIdx.x * kDecWaves + wave;
-  const uint64_t seg0 = group * 64;
-  if (seg0 >= P.n_segs) return;
-  const uint64_t seg = seg0 + lane;
-  const bool valid = seg < P.n_segs;
-  const uint64_t stream_end_bit = (P.origin_byte + P.stream_bytes) * 8;
-  // absolute start bit of this lane's segment and of the one after it
-  uint64_t sbit = stream_end_bit, nbit = stream_end_bit;
-  if (valid) sbit = P.chunk_bit[(seg * kSegSymbols) >> P.chunk_log2] + P.seg_bit[seg];
-  if (seg + 1 < P.n_segs) nbit = P.chunk_bit[((seg + 1) * kSegSymbols) >> P.chunk_log2] + P.seg_bit[seg + 1];
-  const uint64_t B0 = __shfl(sbit, 0, 64);
-  uint64_t B1 = __shfl(nbit, 63, 64);
-  if (seg0 + 64 >= P.n_segs) B1 = stream_end_bit;
-  if (valid && (sbit < P.origin_byte * 8 || sbit >= stream_end_bit || nbit > stream_end_bit || nbit < sbit)) {
-    latch_status(P.status, GHF_E_CORRUPT);
-  }
-  if (__ballot(valid && (sbit < P.origin_byte * 8 || sbit >= stream_end_bit || nbit < sbit))) return;
-
-  // stage the wave's compressed span into LDS as big-endian words
-  const uint64_t byte0 = ((B0 >> 3) & ~15ull);                 // absolute stream byte, 16-aligned
-  uint64_t byte1 = ((B1 + 7) >> 3) + 12;                       // window look-ahead
-  const uint64_t stream_end_byte = P.origin_byte + P.stream_bytes;
-  if (byte1 > stream_end_byte) byte1 = stream_end_byte;
-  const uint64_t span = byte1 - byte0;
-  const uint8_t* src = P.stream + (byte0 - P.origin_byte);
+  const uint64_t ngroups = (P.n_segs + 63) >> 6;
+  const uint64_t gstride = (uint64_t)gridDim.x * kDecWaves;
+  const uint64_t stream_end_bit = P.stream_bytes * 8;
+  const bool out_aligned = (((uintptr_t)P.out) & 15u) == 0;
   uint32_t* in = L.in[wave];
-  const bool staged = span <= (uint64_t)kDecInBytes;
-  if (staged) {
-    for (uint64_t o = (uint64_t)lane * 16; o < span; o += 1024) {
-      uint4 v;
-      if (o + 16 <= span) {
-        v = *reinterpret_cast<const uint4*>(src + o);
-      } else {
-        uint32_t q[4] = {0, 0, 0, 0};
-        for (uint32_t j = 0; o + j < span; ++j) q[j >> 2] |= (uint32_t)src[o + j] << (8 * (j & 3));
-        v = make_uint4(q[0], q[1], q[2], q[3]);
-      }
-      uint32_t* d = in + (o >> 2);
-      d[0] = bswap32(v.x); d[1] = bswap32(v.y); d[2] = bswap32(v.z); d[3] = bswap32(v.w);
-    }
-    // zero the look-ahead words behind the span
-    const uint32_t wend = (uint32_t)((span + 15) >> 4) << 2;
-    if (lane < 4 && wend + lane < (uint32_t)kDecInWords + 4) in[wend + lane] = 0;
-  }
-  wave_sync();
+  uint32_t bad_acc = 0;
 
-  auto fetch = [&](uint64_t widx) -> uint32_t {  // big-endian word `widx` counted from byte0
-    if (staged) return widx < (uint64_t)kDecInWords + 4 ? in[widx] : 0u;
-    const uint64_t b = widx * 4;
-    uint32_t r = 0;
-    for (int k = 0; k < 4; ++k) r = (r << 8) | (b + k < span ? (uint32_t)src[b + k] : 0u);
-    return r;
-  };
-
-  const uint64_t sym0 = seg * kSegSymbols;
-  uint32_t cnt = 0;
-  if (valid) cnt = (P.n_symbols - sym0 >= (uint64_t)kSegSymbols) ? (uint32_t)kSegSymbols : (uint32_t)(P.n_symbols - sym0);
-  uint32_t* orow = L.out[wave] + lane * (kDecRowBytes / 4);
-  uint64_t pos = sbit - byte0 * 8;  // bit position relative to the staged span
-  if (valid) {
-    uint64_t widx = pos >> 5;
-    const uint32_t off = (uint32_t)(pos & 31u);
-    uint64_t window = ((uint64_t)fetch(widx) << 32) | fetch(widx + 1);
-    window <<= off;
-    int avail = 64 - (int)off;
-    widx += 2;
-    uint32_t acc = 0;
-    for (uint32_t i = 0; i < cnt; ++i) {
-      if (avail < 32) {
-        window |= (uint64_t)fetch(widx++) << (32 - avail);
-        avail += 32;
+  for (uint64_t group = (uint64_t)blockIdx.x * kDecWaves + wave; group < ngroups; group += gstride) {
+    const uint64_t seg0 = group * 64;
+    const uint64_t seg = seg0 + lane;
+    const bool valid = seg < P.n_segs;
+    // start bit of this lane's segment and of the one after it (bits counted from d_stream[0])
+    uint64_t sbit = stream_end_bit, nbit = stream_end_bit;
+    if (valid) sbit = P.chunk_bit[(seg * kSegSymbols) >> P.chunk_log2] + P.seg_bit[seg];
+    if (seg + 1 < P.n_segs) nbit = P.chunk_bit[((seg + 1) * kSegSymbols) >> P.chunk_log2] + P.seg_bit[seg + 1];
+    const uint64_t B0 = __shfl(sbit, 0, 64);
+    uint64_t B1 = __shfl(nbit, 63, 64);
+    if (seg0 + 64 >= P.n_segs) {
+      // last group: nothing tells where it ends; bound it by its last segment's worst case (+ end mark)
+      uint64_t m = valid ? sbit + 65ull * (uint64_t)max_len : 0ull;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
       }
-      uint32_t len;
-      const uint32_t sym = dec_symbol(L, window, lut_bits, max_len, len);
-      window <<= len;
-      avail -= (int)len;
-      pos += len;
-      acc |= (sym & 0xFFu) << (8 * (i & 3));
-      if (sym > 255u) latch_status(P.status, GHF_E_CORRUPT);
-      if ((i & 3) == 3) {
-        orow[i >> 2] = acc;
-        acc = 0;
-      }
+      B1 = m < stream_end_bit ? m : stream_end_bit;
     }
-    if (cnt & 3) orow[cnt >> 2] = acc;
-    // the index says where the next segment starts: a cheap end-to-end check of every segment
-    if (seg + 1 < P.n_segs) {
-      if (byte0 * 8 + pos != nbit) latch_status(P.status, GHF_E_CORRUPT);
+    const bool bad = valid && (sbit >= stream_end_bit || nbit > stream_end_bit || nbit < sbit);
+    if (__ballot(bad)) {
+      if (bad) latch_status(P.status, GHF_E_CORRUPT);
+      continue;
+    }
+    // ---- 1. stage the span
+    const uint64_t byte0 = ((B0 >> 3) & ~15ull);
+    uint64_t byte1 = ((B1 + 7) >> 3) + 12;  // window look-ahead
+    if (byte1 > P.stream_bytes) byte1 = P.stream_bytes;
+    const uint64_t span = byte1 - byte0;
+    const uint8_t* src = P.stream + byte0;
+    const bool staged = span <= (uint64_t)kDecInBytes;
+    wave_sync();
+    if (staged) {
+      for (uint64_t o = (uint64_t)lane * 16; o < span; o += 1024) {
+        uint4 v;
+        if (o + 16 <= span) {
+          v = *reinterpret_cast<const uint4*>(src + o);
+        } else {
+          uint32_t q[4] = {0, 0, 0, 0};
+          for (uint32_t j = 0; o + j < span; ++j) q[j >> 2] |= (uint32_t)src[o + j] << (8 * (j & 3));
+          v = make_uint4(q[0], q[1], q[2], q[3]);
+        }
+        *reinterpret_cast<uint4*>(in + (o >> 2)) = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+      }
+      const uint32_t wend = (uint32_t)((span + 15) >> 4) << 2;
+      if (lane < 4 && wend + lane < (uint32_t)kDecInWords + 4) in[wend + lane] = 0;
+    }
+    wave_sync();
+    // ---- 2./3. decode
+    const uint64_t sym0 = seg * kSegSymbols;
+    uint32_t cnt = 0;
+    if (valid) cnt = (P.n_symbols - sym0 >= (uint64_t)kSegSymbols) ? (uint32_t)kSegSymbols : (uint32_t)(P.n_symbols - sym0);
+    const uint64_t pos = sbit - byte0 * 8;
+    const bool all_full = (__ballot(valid && cnt != (uint32_t)kSegSymbols) == 0) && out_aligned;
+    const bool has_next = seg + 1 < P.n_segs;
+    if (staged) {
+      DecIn<true> I{in, src, span};
+      bad_acc |= decode_segment<true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, P.out + sym0, has_next, nbit - sbit);
     } else {
-      if (avail < 32) {
-        window |= (uint64_t)fetch(widx++) << (32 - avail);
-        avail += 32;
-      }
-      uint32_t len;
-      const uint32_t sym = dec_symbol(L, window, lut_bits, max_len, len);
-      if (sym != 256u) latch_status(P.status, GHF_E_CORRUPT);  // canonical_huff_encoder.cc:404: end mark
+      DecIn<false> I{in, src, span};
+      bad_acc |= decode_segment<false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, P.out + sym0, has_next, nbit - sbit);
     }
   }
-  wave_sync();
-  // coalesced write-out of the wave's 4 KiB
-  const uint64_t obase = seg0 * kSegSymbols;
-  const uint64_t obytes = (P.n_symbols - obase >= 4096ull) ? 4096ull : (P.n_symbols - obase);
-  const uint32_t* ob = L.out[wave];
-  if ((((uintptr_t)(P.out + obase)) & 15u) == 0) {
-    for (uint32_t u = lane; u < (uint32_t)(obytes >> 4); u += 64) {
-      const uint32_t* s4 = ob + (u >> 2) * (kDecRowBytes / 4) + (u & 3) * 4;
-      *reinterpret_cast<uint4*>(P.out + obase + (uint64_t)u * 16) = *reinterpret_cast<const uint4*>(s4);
-    }
-    for (uint64_t b = (obytes & ~15ull) + lane; b < obytes; b += 64) {
-      const uint32_t wv = ob[(b >> 6) * (kDecRowBytes / 4) + ((b & 63) >> 2)];
-      P.out[obase + b] = (uint8_t)(wv >> (8 * (b & 3)));
-    }
-  } else {
-    for (uint64_t b = lane; b < obytes; b += 64) {
-      const uint32_t wv = ob[(b >> 6) * (kDecRowBytes / 4) + ((b & 63) >> 2)];
-      P.out[obase + b] = (uint8_t)(wv >> (8 * (b & 3)));
-    }
-  }
+  if (bad_acc & 256u) latch_status(P.status, GHF_E_CORRUPT);  // a data symbol can never be 256
 }
 
 void launch_decode(const DecParams& p, hipStream_t s) {
   const uint64_t groups = (p.n_segs + 63) / 64;
-  const uint64_t blocks = (groups + kDecWaves - 1) / kDecWaves;
+  uint64_t blocks = (groups + kDecWaves - 1) / kDecWaves;
   if (blocks == 0) return;
+  if (blocks > 256 * 5) blocks = 256 * 5;  // persistent: 5 workgroups per CU fit the LDS
   hipLaunchKernelGGL(k_decode, dim3((uint32_t)blocks), dim3(kDecThreads), 0, s, p);
 }
 

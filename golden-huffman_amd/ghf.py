@@ -118,7 +118,7 @@ def lib():
     L.ghf_index_alloc.argtypes = [vp, sz, C.POINTER(Index)]
     L.ghf_index_free.argtypes = [vp, C.POINTER(Index)]
     L.ghf_parse_header.argtypes = [vp, sz, C.POINTER(Code), C.POINTER(sz)]
-    L.ghf_decode.argtypes = [vp, vp, sz, u64, vp, C.POINTER(Index), vp, sz, vp]
+    L.ghf_decode.argtypes = [vp, vp, sz, vp, C.POINTER(Index), vp, sz, vp]
     _lib = L
     return L
 
@@ -146,6 +146,10 @@ def parse_header(host_bytes):
 
 class Context:
     """one ghf_ctx; work is queued on torch's current stream of `device`."""
+
+    EMIT_LAST = EMIT_LAST
+    EMIT_REBASE = EMIT_REBASE
+    compress_bound = staticmethod(compress_bound)
 
     def __init__(self, device=0):
         import torch
@@ -256,12 +260,12 @@ class Context:
             "ghf_compress")
         return d_out, nbytes, d_code
 
-    def decode(self, d_stream, stream_bytes, d_code, index, d_out=None, origin_byte=0):
+    def decode(self, d_stream, stream_bytes, d_code, index, d_out=None):
         if d_out is None:
             d_out = self.empty_u8(index.n_symbols)
         nbytes = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
         self._chk(
-            self.L.ghf_decode(self.h, d_stream.data_ptr(), stream_bytes, origin_byte, d_code.data_ptr(),
+            self.L.ghf_decode(self.h, d_stream.data_ptr(), stream_bytes, d_code.data_ptr(),
                               None if index is None else C.byref(index), d_out.data_ptr(), d_out.numel(), nbytes.data_ptr()),
             "ghf_decode")
         return d_out, nbytes

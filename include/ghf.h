@@ -57,7 +57,8 @@ typedef struct ghf_index {
   uint32_t seg_symbols;   /* symbols per segment (64) */
   uint64_t n_chunks;
   uint64_t n_segs;
-  uint64_t* d_chunk_bit; /* [n_chunks] absolute stream bit (header included) of each chunk's first code */
+  uint64_t* d_chunk_bit; /* [n_chunks] bit offset of each chunk's first code, counted from byte 0 of the d_out the
+                            emit call wrote into (= absolute stream bit, header included, unless GHF_EMIT_REBASE) */
   uint32_t* d_seg_bit;   /* [n_segs]   bit offset of each segment relative to its chunk's first code */
 } ghf_index;
 
@@ -142,11 +143,12 @@ int ghf_parse_header(const uint8_t* h_stream, size_t n, ghf_code* code, size_t* 
 
 /* ---- K6/K7: decode_file of CanonicalHuffDecoder / FastCanonicalHuffDecoder /
  *      TableCanonicalHuffDecoder, include/canonical_huff_encoder.cc:377-419,422-461,466-568 ---------
- * d_stream[0] is stream byte `origin_byte` (0 for a whole .crs2 image).  With an index the decode is
- * block-parallel (length-indexed canonical table in LDS); without one (index == NULL, a .crs2 written
- * by the reference) the index is first rebuilt on the GPU from the bit stream.
+ * d_stream is the buffer an emit call wrote (a whole .crs2 image, or one shard's GHF_EMIT_REBASE buffer)
+ * and index the side-car that call filled: the decode is then block-parallel (length-indexed canonical
+ * table in LDS).  Without one (index == NULL, e.g. a .crs2 written by the reference; d_stream must then
+ * be a whole .crs2 image) the index is first rebuilt on the GPU from the bit stream.
  * d_out_bytes: device u64 = decoded size. */
-int ghf_decode(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, uint64_t origin_byte, const ghf_code* d_code,
+int ghf_decode(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code,
                const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes);
 
 #ifdef __cplusplus
