@@ -124,61 +124,73 @@ void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint
 // The reference keeps symbol INDICES in a std::priority_queue ordered by the live frequency table
 // (include/canonical_huff_encoder.h:58-70).  Which of several equal-weight nodes is popped first is
 // decided by libstdc++'s heap layout, and that decides the code lengths, so the heap is emulated
-// step for step (lane 0: __push_heap / __adjust_heap as in <bits/stl_heap.h>), keys stored beside
-// the indices so one sift level is one LDS round trip.  The "+1 for every member of both chains"
-// walks of canonical_huff_encoder.cc:316-329 are done by all 64 lanes: every symbol remembers the
-// surviving index of its group.
+// step for step (lane 0: __push_heap / __adjust_heap as in <bits/stl_heap.h>).  The "+1 for every
+// member of both chains" walks of canonical_huff_encoder.cc:316-329 become a recorded merge tree whose
+// leaf depths all 64 lanes read off in parallel afterwards.
 // ------------------------------------------------------------------------------------------------
+// Heap entry = (frequency << 9) | symbol index in ONE 64-bit word, so a sift level moves one word and a
+// parent's two children (and its four grandchildren) are one (two) aligned 16-byte LDS reads.
+// The reference's comparator looks at the frequency only -- equal frequencies must compare EQUAL, the
+// index must not break ties: comp(a, b) = freq[a] > freq[b]  <=>  ea > (eb | 511).
+// Heap position p lives in slot p + 1 so that the child pair (2p+1, 2p+2) sits on a 16-byte boundary.
 struct HeapLds {
-  long long key[GHF_NSYM + 3];
-  int val[GHF_NSYM + 3];
-  int n;
+  alignas(16) unsigned long long slot[528];
+  uint16_t parent[GHF_NSYM + 256 + 7];  // Huffman tree: node -> parent node (0 = none); leaves 0..256, merges 257..
+  uint16_t cur[GHF_NSYM + 3];           // symbol index kept in the heap -> the tree node it currently stands for
 };
 
-__device__ __forceinline__ void heap_sift_up(HeapLds& h, int hole, int v, long long k) {
-  // libstdc++ __push_heap(first, hole, top = 0, value, comp) with comp(a,b) = freq[a] > freq[b]
+typedef unsigned long long u64t;
+struct alignas(16) U64x2 { u64t x, y; };
+
+__device__ __forceinline__ bool heap_gt(u64t a, u64t b) { return a > (b | 511ull); }  // freq(a) > freq(b)
+
+__device__ __forceinline__ void heap_sift_up(HeapLds& h, int hole, u64t e) {
+  // libstdc++ __push_heap(first, hole, top = 0, value, comp)
   while (hole > 0) {
     const int parent = (hole - 1) >> 1;
-    const long long pk = h.key[parent];
-    if (!(pk > k)) break;
-    h.key[hole] = pk;
-    h.val[hole] = h.val[parent];
+    const u64t pe = h.slot[parent + 1];
+    if (!heap_gt(pe, e)) break;
+    h.slot[hole + 1] = pe;
     hole = parent;
   }
-  h.key[hole] = k;
-  h.val[hole] = v;
+  h.slot[hole + 1] = e;
 }
 
-__device__ __forceinline__ void heap_push(HeapLds& h, int v, long long k) {
-  const int pos = h.n;
-  h.n = pos + 1;
-  heap_sift_up(h, pos, v, k);
-}
-
-__device__ __forceinline__ void heap_pop(HeapLds& h) {
-  // std::pop_heap + pop_back: a[0] leaves, __adjust_heap(first, 0, len = n-1, value = old back)
-  const int len = h.n - 1;
-  h.n = len;
-  if (len < 1) return;
-  const int v = h.val[len];
-  const long long k = h.key[len];
-  int hole = 0, child = 0;
+// std::pop_heap + pop_back: a[0] leaves, then __adjust_heap(first, 0, len = n-1, value = old back): the hole
+// walks to the bottom always taking the child for which comp(right, left) is false -> right, else left (two
+// levels per LDS round trip: the grandchildren are fetched together with the children), the lone left
+// child of an even-length heap is handled, then the displaced value is pushed up from the hole.
+__device__ __forceinline__ u64t heap_pop(HeapLds& h, int& n) {
+  const u64t top = h.slot[1];
+  const int len = n - 1;
+  n = len;
+  if (len < 1) return top;
+  const u64t value = h.slot[len + 1];
+  int hole = 0;
   const int lim = (len - 1) >> 1;
-  while (child < lim) {
-    child = 2 * (child + 1);
-    const long long kr = h.key[child], kl = h.key[child - 1];
-    if (kr > kl) --child;  // comp(right, left) -> take left, else right
-    h.key[hole] = (kr > kl) ? kl : kr;
-    h.val[hole] = h.val[child];
+  while (hole < lim) {
+    const U64x2 c = *reinterpret_cast<const U64x2*>(&h.slot[2 * hole + 2]);   // positions 2h+1, 2h+2
+    const U64x2 g0 = *reinterpret_cast<const U64x2*>(&h.slot[4 * hole + 4]);  // positions 4h+3, 4h+4
+    const U64x2 g1 = *reinterpret_cast<const U64x2*>(&h.slot[4 * hole + 6]);  // positions 4h+5, 4h+6
+    const bool left = heap_gt(c.y, c.x);
+    const int child = 2 * hole + (left ? 1 : 2);
+    h.slot[hole + 1] = left ? c.x : c.y;
     hole = child;
+    if (hole < lim) {
+      const U64x2 g = left ? g0 : g1;
+      const bool left2 = heap_gt(g.y, g.x);
+      const int child2 = 2 * hole + (left2 ? 1 : 2);
+      h.slot[hole + 1] = left2 ? g.x : g.y;
+      hole = child2;
+    }
   }
-  if ((len & 1) == 0 && child == ((len - 2) >> 1)) {
-    child = 2 * (child + 1);
-    h.key[hole] = h.key[child - 1];
-    h.val[hole] = h.val[child - 1];
+  if ((len & 1) == 0 && hole == ((len - 2) >> 1)) {
+    const int child = 2 * (hole + 1);
+    h.slot[hole + 1] = h.slot[child];  // position child - 1
     hole = child - 1;
   }
-  heap_sift_up(h, hole, v, k);
+  heap_sift_up(h, hole, value);
+  return top;
 }
 
 struct CodeLds {
@@ -191,68 +203,75 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
   __shared__ HeapLds heap;
   __shared__ long long freq[GHF_NSYM + 3];
   __shared__ CodeLds cl;
+  __shared__ int s_ndata;
   const int lane = threadIdx.x;
-  for (int s = lane; s < GHF_NSYM; s += 64) freq[s] = (long long)hist[s];
+  for (int s = lane; s < GHF_NSYM; s += 64) {
+    freq[s] = (long long)hist[s];
+    heap.cur[s] = (uint16_t)s;
+  }
+  for (int i = lane; i < GHF_NSYM + 256 + 7; i += 64) heap.parent[i] = 0;
   for (int i = lane; i < (int)(sizeof(ghf_code) / 4); i += 64) reinterpret_cast<uint32_t*>(&cl.code)[i] = 0;
   if (lane < 40) cl.num[lane] = 0;
   __syncthreads();
 
-  // symbols owned by this lane: s_j = lane + 64 j (j = 0..4; s = 256 is lane 0, j = 4)
-  uint32_t grp[5], len[5];
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    grp[j] = (uint32_t)(lane + 64 * j);
-    len[j] = 0;
-  }
-  int hn = 0, ndata = 0;
+  // ---- K2: get_encoding_length, canonical_huff_encoder.cc:289-345.  Strictly sequential (which of several
+  // equal-weight nodes pops first is decided by the heap layout), so one lane runs it; the merges are
+  // recorded as a tree and all lanes read the depths off afterwards.
   if (lane == 0) {
-    heap.n = 0;
-    for (int s = 0; s < GHF_NSYM; ++s) {  // canonical_huff_encoder.cc:301-306: ascending index, zero counts skipped
+    int n = 0, ndata = 0;
+    for (int s = 0; s < GHF_NSYM; ++s) {  // .cc:301-306: ascending index, zero counts skipped
       const long long f = freq[s];
       if (f) {
-        heap_push(heap, s, f);
+        heap_sift_up(heap, n, ((u64t)f << 9) | (u64t)s);  // priority_queue::push
+        ++n;
         if (s < 256) ++ndata;
       }
     }
-    hn = heap.n;
+    s_ndata = ndata;
+    const int times = n - 1;  // .cc:309
+    for (int t = 0; t < times; ++t) {
+      const u64t e1 = heap_pop(heap, n);  // .cc:311-314
+      const u64t e2 = heap_pop(heap, n);
+      const int s1 = (int)(e1 & 511u), s2 = (int)(e2 & 511u);
+      const int node = GHF_NSYM + t;
+      heap.parent[heap.cur[s1]] = (uint16_t)node;  // .cc:316-329: both groups one level deeper ...
+      heap.parent[heap.cur[s2]] = (uint16_t)node;
+      heap.cur[s2] = (uint16_t)node;               // ... and merged under the second popped index
+      const u64t f = (e1 >> 9) + (e2 >> 9);        // .cc:331
+      heap_sift_up(heap, n, (f << 9) | (u64t)s2);  // .cc:333
+      ++n;
+    }
   }
-  hn = __shfl(hn, 0, 64);
-  ndata = __shfl(ndata, 0, 64);
-  if (ndata == 0) {  // empty input: undefined in the reference
+  __syncthreads();
+  if (s_ndata == 0) {  // empty input: undefined in the reference
     if (lane == 0) latch_status(status, GHF_E_EMPTY);
     return;
   }
-  const int times = hn - 1;  // canonical_huff_encoder.cc:309
-  for (int t = 0; t < times; ++t) {
-    int t1 = 0, t2 = 0;
-    if (lane == 0) {
-      t1 = heap.val[0];
-      heap_pop(heap);
-      t2 = heap.val[0];
-      heap_pop(heap);
-    }
-    t1 = __shfl(t1, 0, 64);
-    t2 = __shfl(t2, 0, 64);
+  // code length = depth of the leaf; symbols owned by this lane: s_j = lane + 64 j (s = 256 is lane 0, j = 4)
+  uint32_t len[5], node[5];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {  // .cc:316-329: both groups one level deeper, merged under the second popped
-      const bool m = (grp[j] == (uint32_t)t1) || (grp[j] == (uint32_t)t2);
-      if (m) {
+  for (int j = 0; j < 5; ++j) {
+    len[j] = 0;
+    node[j] = (uint32_t)(lane + 64 * j);
+    if (node[j] >= GHF_NSYM) node[j] = GHF_NSYM + 256 + 1;  // parent == 0 there
+  }
+  for (int step = 0; step < 256; ++step) {
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const uint32_t p = heap.parent[node[j]];
+      if (p) {
+        node[j] = p;
         len[j] += 1;
-        grp[j] = (uint32_t)t2;
+        any = true;
       }
     }
-    if (lane == 0) {  // .cc:331-333: survivor = second popped, re-pushed with the summed weight
-      const long long f = freq[t1] + freq[t2];
-      freq[t2] = f;
-      heap_push(heap, t2, f);
-    }
+    if (!__ballot(any)) break;
   }
-  // symbols that never entered the heap keep length 0
   uint32_t mx = 0;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
-    const int s = lane + 64 * j;
-    if (s >= GHF_NSYM) len[j] = 0;
+    if (lane + 64 * j >= GHF_NSYM) len[j] = 0;  // lanes past symbol 256 own nothing
     mx = len[j] > mx ? len[j] : mx;
   }
 #pragma unroll
@@ -397,35 +416,39 @@ __global__ __launch_bounds__(256) void k_chunk_bits_direct(const uint8_t* __rest
   }
 }
 
-// in-place exclusive scan of v[0..count), v[count] = total, *total_out = total
+// in-place exclusive scan of v[0..count), v[count] = total, *total_out = total.  One workgroup; thread t owns
+// a run of consecutive elements, so there is a single block-wide scan whatever the count.
 __global__ __launch_bounds__(1024) void k_scan(uint64_t* __restrict__ v, uint32_t count, uint64_t* __restrict__ total_out) {
   __shared__ unsigned long long wsum[16];
-  __shared__ unsigned long long carry_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < count; base += 1024) {
-    const uint32_t i = base + tid;
-    const unsigned long long x = (i < count) ? v[i] : 0ull;
-    unsigned long long s = x;
+  const uint32_t ipt = (count + 1023u) / 1024u;
+  const uint32_t lo = tid * ipt;
+  const uint32_t hi = (lo + ipt < count) ? lo + ipt : count;
+  unsigned long long mine = 0;
+  for (uint32_t i = lo; i < hi; ++i) mine += v[i];
+  unsigned long long s = mine;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned long long t = __shfl_up(s, d, 64);
-      if (lane >= d) s += t;
-    }
-    if (lane == 63) wsum[w] = s;
-    __syncthreads();
-    unsigned long long woff = 0;
-    for (int k = 0; k < w; ++k) woff += wsum[k];
-    const unsigned long long carry = carry_s;
-    if (i < count) v[i] = carry + woff + s - x;
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + woff + s;
-    __syncthreads();
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long t = __shfl_up(s, d, 64);
+    if (lane >= d) s += t;
+  }
+  if (lane == 63) wsum[w] = s;
+  __syncthreads();
+  unsigned long long woff = 0, total = 0;
+  for (int k = 0; k < 16; ++k) {
+    const unsigned long long x = wsum[k];
+    if (k < w) woff += x;
+    total += x;
+  }
+  unsigned long long run = woff + s - mine;
+  for (uint32_t i = lo; i < hi; ++i) {
+    const unsigned long long x = v[i];
+    v[i] = run;
+    run += x;
   }
   if (tid == 0) {
-    v[count] = carry_s;
-    if (total_out) *total_out = carry_s;
+    v[count] = total;
+    if (total_out) *total_out = total;
   }
 }
 
