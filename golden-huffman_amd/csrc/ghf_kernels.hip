@@ -77,18 +77,28 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
     const uint4* pv = reinterpret_cast<const uint4*>(p + head);
     const uint64_t nvec = (len - head) >> 4;
     uint64_t i = tid;
-    // 4 x 16 B in flight per lane, each load instruction fully coalesced (1 KiB per wave)
-    for (; i + 3 * kHistThreads < nvec; i += 4 * kHistThreads) {
-      const uint4 v0 = pv[i];
-      const uint4 v1 = pv[i + kHistThreads];
-      const uint4 v2 = pv[i + 2 * kHistThreads];
-      const uint4 v3 = pv[i + 3 * kHistThreads];
-      hist_vec(lh, rep, v0);
-      hist_vec(lh, rep, v1);
-      hist_vec(lh, rep, v2);
-      hist_vec(lh, rep, v3);
+    // software pipeline without register moves: while A/B are counted, C/D are in flight and vice versa
+    // (every load instruction is a fully coalesced 1 KiB per wave)
+    constexpr uint64_t S = kHistThreads;
+    if (i + 3 * S < nvec) {
+      uint4 A = pv[i], B = pv[i + S];
+      for (; i + 7 * S < nvec; i += 4 * S) {
+        const uint4 C = pv[i + 2 * S], D = pv[i + 3 * S];
+        hist_vec(lh, rep, A);
+        hist_vec(lh, rep, B);
+        A = pv[i + 4 * S];
+        B = pv[i + 5 * S];
+        hist_vec(lh, rep, C);
+        hist_vec(lh, rep, D);
+      }
+      const uint4 C = pv[i + 2 * S], D = pv[i + 3 * S];
+      hist_vec(lh, rep, A);
+      hist_vec(lh, rep, B);
+      hist_vec(lh, rep, C);
+      hist_vec(lh, rep, D);
+      i += 4 * S;
     }
-    for (; i < nvec; i += kHistThreads) {
+    for (; i < nvec; i += S) {
       const uint4 v0 = pv[i];
       hist_vec(lh, rep, v0);
     }
@@ -571,21 +581,39 @@ __device__ __forceinline__ void pack_pass(WaveOut& W, const typename E::T (&e)[1
   wave_sync();
 }
 
+// one wave iteration: 16 table entries per lane -> bits in the staging area -> whole units to HBM
 template <typename E>
-__device__ __forceinline__ void emit_iteration(WaveOut& W, const typename E::T (&e)[16], uint32_t T, int lane,
-                                               uint32_t* seg_out, uint64_t relbits, bool seg_valid, uint32_t& total_out) {
+__device__ __forceinline__ void emit_iteration(WaveOut& W, const typename E::T (&e)[16], int lane, uint32_t* seg_out,
+                                               uint64_t relbits, bool seg_valid, uint32_t& total_out) {
+  uint32_t T = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) T += E::len(e[j]);
   const uint32_t incl = wave_incl_scan_u32(T, lane);
   const uint32_t excl = incl - T;
   const uint32_t total = __shfl(incl, 63, 64);
   total_out = total;
   if (seg_out && seg_valid && (lane & 3) == 0) *seg_out = (uint32_t)(relbits + excl);
-  if (W.carry + total + 128u <= (uint32_t)kStageCapBits) {
-    pack_pass<E>(W, e, true, W.carry + excl, total, lane == 0, lane);
-  } else {
-    // rare: long codes.  Two half-wave passes, each at most 512 x 32 bits.
-    const uint32_t half_total = __shfl(incl, 31, 64);
-    pack_pass<E>(W, e, lane < 32, W.carry + excl, half_total, lane == 0, lane);
-    pack_pass<E>(W, e, lane >= 32, W.carry + (excl - half_total), total - half_total, lane == 32, lane);
+  // normally one pass; only with long codes (> 16 bits on average) the 1024 symbols are packed as two half-waves,
+  // each at most 512 x 32 bits, so the staging area never overflows
+  const bool split = W.carry + total + 128u > (uint32_t)kStageCapBits;
+  const uint32_t half_total = __shfl(incl, 31, 64);
+  const int npass = split ? 2 : 1;
+  for (int p = 0; p < npass; ++p) {
+    const bool second = p == 1;
+    const bool active = !split || ((lane >= 32) == second);
+    const uint32_t base = second ? half_total : 0u;
+    const uint32_t ptotal = split ? (second ? total - half_total : half_total) : total;
+    pack_pass<E>(W, e, active, W.carry + (excl - base), ptotal, lane == (second ? 32 : 0), lane);
+  }
+}
+
+template <typename E>
+__device__ __forceinline__ void lookup16(const typename E::T* tab, const uint4& v, int lane, typename E::T (&e)[16]) {
+  const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t b = (vv[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+    e[j] = tab[E::slot(b, (uint32_t)lane)];
   }
 }
 
@@ -609,60 +637,82 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, cons
   if (lane == 0 && P.chunk_bit) P.chunk_bit[c] = Pc - origin_byte * 8;  // relative to d_out[0]
   wave_sync();
   uint64_t relbits = 0;
-  const uint64_t niter = (nsym + kSymPerIter - 1) / kSymPerIter;
-  uint4 vnext = make_uint4(0, 0, 0, 0);
-  if (aligned && nsym >= (uint64_t)kSymPerIter) vnext = reinterpret_cast<const uint4*>(pin)[lane];
-  for (uint64_t it = 0; it < niter; ++it) {
-    const uint64_t sb = it * kSymPerIter;
-    const uint64_t rem = nsym - sb;
-    uint4 v;
-    uint32_t cnt = 16;
-    if (aligned && rem >= (uint64_t)kSymPerIter) {
-      v = vnext;
-      if (rem >= 2ull * kSymPerIter) vnext = reinterpret_cast<const uint4*>(pin + sb + kSymPerIter)[lane];
-    } else {
-      // ragged tail or unaligned input: byte loads, never past the end of the buffer
-      const uint64_t lo = (uint64_t)lane * 16;
-      cnt = rem > lo ? (rem - lo >= 16 ? 16u : (uint32_t)(rem - lo)) : 0u;
-      uint32_t q[4] = {0, 0, 0, 0};
-      for (uint32_t j = 0; j < cnt; ++j) q[j >> 2] |= (uint32_t)pin[sb + lo + j] << (8 * (j & 3));
-      v = make_uint4(q[0], q[1], q[2], q[3]);
+  const uint64_t nfull = aligned ? (nsym / kSymPerIter) : 0;
+  const uint4* pv = reinterpret_cast<const uint4*>(pin) + lane;
+  uint32_t* const segp = P.seg_bit ? P.seg_bit + ((sym0 + (uint64_t)lane * 16) >> 6) : nullptr;
+  uint64_t it = 0;
+  // ---- full 1 KiB tiles, two per trip.  While tile `it` is packed, the loads of tiles it+1 and it+2 are in flight;
+  //      A and B are each re-loaded right after they were consumed, so no register ever has to be copied while
+  //      its load is pending (the last prefetches are clamped to the last full tile and simply unused).
+  if (nfull >= 2) {
+    uint4 A = pv[0], B = pv[64];
+    for (; it + 1 < nfull; it += 2) {
+      {
+        const uint4 v = A;
+        const uint64_t nx = (it + 2 < nfull) ? it + 2 : nfull - 1;
+        A = pv[nx * 64];
+        ET e[16];
+        lookup16<E>(tab, v, lane, e);
+        uint32_t total;
+        emit_iteration<E>(W, e, lane, segp ? segp + it * 16 : nullptr, relbits, true, total);
+        relbits += total;
+      }
+      {
+        const uint4 v = B;
+        const uint64_t nx = (it + 3 < nfull) ? it + 3 : nfull - 1;
+        B = pv[nx * 64];
+        ET e[16];
+        lookup16<E>(tab, v, lane, e);
+        uint32_t total;
+        emit_iteration<E>(W, e, lane, segp ? segp + (it + 1) * 16 : nullptr, relbits, true, total);
+        relbits += total;
+      }
     }
-    ET e[16];
-    const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint32_t b = (vv[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-      e[j] = tab[E::slot(b, (uint32_t)lane)];
-    }
-    if (cnt < 16) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if ((uint32_t)j >= cnt) e[j] = 0;
-    }
-    uint32_t T = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) T += E::len(e[j]);
-    uint32_t total;
-    uint32_t* seg_out = P.seg_bit ? P.seg_bit + ((sym0 + sb + (uint64_t)lane * 16) >> 6) : nullptr;
-    emit_iteration<E>(W, e, T, lane, seg_out, relbits, cnt != 0, total);
-    relbits += total;
   }
-  if ((P.flags & GHF_EMIT_LAST) && c + 1 == P.nchunks) {
-    // canonical_huff_encoder.cc:255-257: end mark, then buffer.h:277-280 pads with 1s to the byte
-    const uint32_t el = P.code->length[GHF_NSYM - 1], ec = P.code->codeword[GHF_NSYM - 1];
-    const uint32_t pad = (uint32_t)((0 - (Pc + relbits + el)) & 7u);
+  // ---- whatever is left: an odd full tile, the ragged tail, unaligned input, and -- on the stream's last chunk --
+  //      one extra pass for the end mark and the padding (canonical_huff_encoder.cc:255-257, buffer.h:277-280)
+  const uint64_t niter = (nsym + kSymPerIter - 1) / kSymPerIter;
+  const bool last = (P.flags & GHF_EMIT_LAST) && c + 1 == P.nchunks;
+  const uint64_t nsteps = niter + (last ? 1 : 0);
+  for (; it < nsteps; ++it) {
     ET e[16];
+    bool seg_valid = false;
+    uint32_t* seg_out = nullptr;
+    if (it < niter) {
+      const uint64_t sb = it * kSymPerIter;
+      const uint64_t rem = nsym - sb;
+      uint4 v;
+      uint32_t cnt = 16;
+      if (aligned && rem >= (uint64_t)kSymPerIter) {
+        v = pv[it * 64];
+      } else {  // byte loads, never past the end of the buffer
+        const uint64_t lo = (uint64_t)lane * 16;
+        cnt = rem > lo ? (rem - lo >= 16 ? 16u : (uint32_t)(rem - lo)) : 0u;
+        uint32_t q[4] = {0, 0, 0, 0};
+        for (uint32_t j = 0; j < cnt; ++j) q[j >> 2] |= (uint32_t)pin[sb + lo + j] << (8 * (j & 3));
+        v = make_uint4(q[0], q[1], q[2], q[3]);
+      }
+      lookup16<E>(tab, v, lane, e);
+      if (cnt < 16) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) e[j] = 0;
-    uint32_t T = 0;
-    if (lane == 0) {
-      e[0] = E::make(ec, el);
-      e[1] = E::make((1u << pad) - 1u, pad);
-      T = el + pad;
+        for (int j = 0; j < 16; ++j)
+          if ((uint32_t)j >= cnt) e[j] = 0;
+      }
+      seg_valid = cnt != 0;
+      seg_out = segp ? segp + it * 16 : nullptr;
+    } else {
+      const uint32_t el = P.code->length[GHF_NSYM - 1], ec = P.code->codeword[GHF_NSYM - 1];
+      const uint32_t pad = (uint32_t)((0 - (Pc + relbits + el)) & 7u);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) e[j] = 0;
+      if (lane == 0) {
+        e[0] = E::make(ec, el);
+        e[1] = E::make((1u << pad) - 1u, pad);
+      }
     }
     uint32_t total;
-    emit_iteration<E>(W, e, T, lane, nullptr, 0, false, total);
+    emit_iteration<E>(W, e, lane, seg_out, relbits, seg_valid, total);
+    relbits += total;
   }
   // the chunk's last, incomplete unit is shared with the next chunk (or is the end of the stream)
   if (W.carry) or_unit_words(W.out_units + W.unit_base, st, lane);
@@ -691,7 +741,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EmitParams P) {
     }
   }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell the compiler it is wave-uniform (SGPR)
   const uint32_t c = blockIdx.x * kEmitWaves + wave;
   if (c >= P.nchunks) return;
   const uint64_t start_bit = P.d_start_bit ? *P.d_start_bit : 8ull * (1040ull + 8ull * (uint64_t)max_len);
@@ -941,7 +992,8 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(DecParams P) {
   }
   for (int i = tid; i < GHF_NSYM; i += kDecThreads) L.symbol[i] = P.dt->symbol[i];
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar loop control
   const uint64_t ngroups = (P.n_segs + 63) >> 6;
   const uint64_t gstride = (uint64_t)gridDim.x * kDecWaves;
   const uint64_t stream_end_bit = P.stream_bytes * 8;

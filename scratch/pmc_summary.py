@@ -1,0 +1,13 @@
+import csv, glob, sys, collections
+tag = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob('gpurun_out/pmc_%s/p*/**/*counter_collection.csv' % tag, recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'].split('(')[0]
+        if not k.startswith('ghf::'): continue
+        acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
+for k in sorted(acc):
+    print(k)
+    for c in sorted(acc[k]):
+        v = acc[k][c]
+        print('   %-26s n=%-3d avg=%.4g' % (c, len(v), sum(v)/len(v)))
