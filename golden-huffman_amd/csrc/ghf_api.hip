@@ -31,7 +31,14 @@ struct ghf_ctx {
   uint64_t* d_hist = nullptr;   // [257]
   ghf_code* d_code = nullptr;   // scratch tables for ghf_compress
   DecTables* d_dt = nullptr;
-  uint64_t* d_u64 = nullptr;    // [8] scratch scalars: 0 total_bits, 1..2 end, ...
+  uint64_t* d_u64 = nullptr;    // [8] scratch scalars: 0 total_bits, 1..2 end, 3 n_symbols, 4 eof_sub, 5 changed
+  uint64_t* h_u64 = nullptr;    // [8] pinned mirror
+  // K6 workspace (foreign streams)
+  void* d_sync = nullptr;
+  size_t sync_cap = 0;  // bytes
+  ghf_index fidx = {};  // side-car rebuilt for the last foreign stream
+  uint64_t* d_seg_abs = nullptr;
+  size_t fidx_cap_segs = 0, fidx_cap_chunks = 0;
   std::string err;
 };
 
@@ -128,6 +135,7 @@ int ghf_ctx_create(int device, ghf_ctx** out) {
   GHF_STEP(hipMalloc(&c->d_code, sizeof(ghf_code)));
   GHF_STEP(hipMalloc(&c->d_dt, sizeof(DecTables)));
   GHF_STEP(hipMalloc(&c->d_u64, 8 * sizeof(uint64_t)));
+  GHF_STEP(hipHostMalloc(&c->h_u64, 8 * sizeof(uint64_t), hipHostMallocDefault));
   GHF_STEP(hipMemset(c->d_status, 0, sizeof(int)));
 #undef GHF_STEP
   if (e != hipSuccess) {
@@ -152,6 +160,11 @@ int ghf_ctx_destroy(ghf_ctx* c) {
   if (c->d_code) (void)hipFree(c->d_code);
   if (c->d_dt) (void)hipFree(c->d_dt);
   if (c->d_u64) (void)hipFree(c->d_u64);
+  if (c->h_u64) (void)hipHostFree(c->h_u64);
+  if (c->d_sync) (void)hipFree(c->d_sync);
+  if (c->d_seg_abs) (void)hipFree(c->d_seg_abs);
+  if (c->fidx.d_chunk_bit) (void)hipFree(c->fidx.d_chunk_bit);
+  if (c->fidx.d_seg_bit) (void)hipFree(c->fidx.d_seg_bit);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return GHF_OK;
@@ -444,17 +457,115 @@ int ghf_parse_header(const uint8_t* h, size_t n, ghf_code* code, size_t* header_
   return GHF_OK;
 }
 
+// K6: rebuild the side-car of a stream that came without one (e.g. a .crs2 written by the reference).
+// Synchronises with the host a few times (convergence flag, symbol count); fills c->fidx.
+static int rebuild_index(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code, size_t cap) {
+  ghf_code* hc = new (std::nothrow) ghf_code;
+  if (!hc) return GHF_E_NOMEM;
+  hipError_t e = hipMemcpyAsync(hc, d_code, sizeof(ghf_code), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  const int max_len = hc->max_len;
+  delete hc;
+  if (e != hipSuccess) return fail(c, GHF_E_HIP, "copy tables to host", e);
+  if (max_len < 1 || max_len > 32) return fail(c, GHF_E_FORMAT, "bad max_len in tables");
+  const size_t hdr = ghf_header_bytes(max_len);
+  if (stream_bytes <= hdr) return fail(c, GHF_E_FORMAT, "stream shorter than its header");
+  SyncParams p;
+  p.stream = d_stream;
+  p.stream_bytes = stream_bytes;
+  p.body_bit0 = (uint64_t)hdr * 8;
+  p.dt = c->d_dt;
+  p.nsub = ((stream_bytes - hdr) * 8 + 511) / 512;
+  const size_t ntiles = (p.nsub + 255) / 256;
+  // carve the workspace
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  const size_t o_start = carve((p.nsub + 1) * 2), o_used = carve(p.nsub * 2), o_cnt = carve(p.nsub * 4), o_eof = carve(p.nsub),
+               o_tile = carve((ntiles + 2) * 8);
+  if (off > c->sync_cap) {
+    if (c->d_sync) (void)hipFree(c->d_sync);
+    c->d_sync = nullptr;
+    c->sync_cap = 0;
+    GHF_HIP(c, hipMalloc(&c->d_sync, off));
+    c->sync_cap = off;
+  }
+  uint8_t* ws = static_cast<uint8_t*>(c->d_sync);
+  p.start = reinterpret_cast<uint16_t*>(ws + o_start);
+  p.used = reinterpret_cast<uint16_t*>(ws + o_used);
+  p.cnt = reinterpret_cast<uint32_t*>(ws + o_cnt);
+  p.eof = ws + o_eof;
+  p.tile_sum = reinterpret_cast<uint64_t*>(ws + o_tile);
+  p.changed = reinterpret_cast<uint32_t*>(c->d_u64 + 5);
+  p.eof_sub = c->d_u64 + 4;
+  GHF_HIP(c, hipMemsetAsync(p.start, 0, (p.nsub + 1) * 2, c->stream));
+  GHF_HIP(c, hipMemsetAsync(p.used, 0xFF, p.nsub * 2, c->stream));
+  GHF_HIP(c, hipMemsetAsync(p.eof, 0, p.nsub, c->stream));
+  launch_store_u64(p.eof_sub, nullptr, p.nsub, c->stream);
+  // passes until no boundary guess moves (self-synchronisation: a handful of passes in practice)
+  for (uint64_t pass = 0;; ++pass) {
+    if (pass > p.nsub + 2) return fail(c, GHF_E_CORRUPT, "self-synchronisation did not converge");
+    GHF_HIP(c, hipMemsetAsync(p.changed, 0, 8, c->stream));
+    launch_sync_pass(p, c->stream);
+    GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 5, p.changed, 8, hipMemcpyDeviceToHost, c->stream));
+    GHF_HIP(c, hipStreamSynchronize(c->stream));
+    if ((uint32_t)c->h_u64[5] == 0) break;
+  }
+  launch_sync_counts(p, c->d_u64 + 3, c->stream);
+  GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 3, c->d_u64 + 3, 16, hipMemcpyDeviceToHost, c->stream));
+  GHF_HIP(c, hipStreamSynchronize(c->stream));
+  const uint64_t n = c->h_u64[3], eof_sub = c->h_u64[4];
+  if (eof_sub >= p.nsub) return fail(c, GHF_E_CORRUPT, "no end mark in the stream");
+  if (n > cap) return fail(c, GHF_E_CAP, "ghf_decode: output capacity below the decoded size");
+  // size the side-car
+  ghf_index& ix = c->fidx;
+  const uint32_t cl = chunk_log2_for(n);
+  const uint64_t n_chunks = (n + ((uint64_t)1 << cl) - 1) >> cl, n_segs = (n + kSegSymbols - 1) / kSegSymbols;
+  if (n_segs > c->fidx_cap_segs) {
+    if (ix.d_seg_bit) (void)hipFree(ix.d_seg_bit);
+    if (c->d_seg_abs) (void)hipFree(c->d_seg_abs);
+    ix.d_seg_bit = nullptr;
+    c->d_seg_abs = nullptr;
+    c->fidx_cap_segs = 0;
+    GHF_HIP(c, hipMalloc(&ix.d_seg_bit, n_segs * sizeof(uint32_t)));
+    GHF_HIP(c, hipMalloc(&c->d_seg_abs, n_segs * sizeof(uint64_t)));
+    c->fidx_cap_segs = n_segs;
+  }
+  if (n_chunks > c->fidx_cap_chunks) {
+    if (ix.d_chunk_bit) (void)hipFree(ix.d_chunk_bit);
+    ix.d_chunk_bit = nullptr;
+    c->fidx_cap_chunks = 0;
+    GHF_HIP(c, hipMalloc(&ix.d_chunk_bit, n_chunks * sizeof(uint64_t)));
+    c->fidx_cap_chunks = n_chunks;
+  }
+  ix.n_symbols = n;
+  ix.chunk_symbols = 1u << cl;
+  ix.seg_symbols = kSegSymbols;
+  ix.n_chunks = n_chunks;
+  ix.n_segs = n_segs;
+  if (n) launch_sync_index(p, c->d_seg_abs, n_segs, cl, ix.d_chunk_bit, ix.d_seg_bit, c->stream);
+  GHF_HIP(c, hipGetLastError());
+  return GHF_OK;
+}
+
 int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code,
                const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes) {
   if (!c || !d_stream || !d_code || !d_out) return GHF_E_INVAL;
   if (!aligned16(d_stream)) return fail(c, GHF_E_INVAL, "d_stream must be 16-byte aligned");
-  if (!index) return fail(c, GHF_E_INVAL, "ghf_decode: decode without a side-car index is not implemented yet");
+  GHF_HIP(c, hipSetDevice(c->device));
+  launch_build_decode_tables(d_code, c->d_dt, c->d_status, c->stream);
+  if (!index) {
+    const int rc = rebuild_index(c, d_stream, stream_bytes, d_code, cap);
+    if (rc) return rc;
+    index = &c->fidx;
+  }
   if (!index->d_chunk_bit || !index->d_seg_bit || index->seg_symbols != (uint32_t)kSegSymbols ||
       (index->chunk_symbols & (index->chunk_symbols - 1)) || index->chunk_symbols < (uint32_t)kSegSymbols)
     return fail(c, GHF_E_INVAL, "ghf_decode: malformed index");
   if (cap < index->n_symbols) return fail(c, GHF_E_CAP, "ghf_decode: output capacity below n_symbols");
-  GHF_HIP(c, hipSetDevice(c->device));
-  launch_build_decode_tables(d_code, c->d_dt, c->d_status, c->stream);
   DecParams p;
   p.stream = d_stream;
   p.stream_bytes = stream_bytes;

@@ -78,7 +78,27 @@ struct DecParams {
   int* status;
 };
 
+// K6: side-car reconstruction for foreign streams
+struct SyncParams {
+  const uint8_t* stream;
+  uint64_t stream_bytes;
+  uint64_t body_bit0;  // first body bit = 8 * header bytes
+  const DecTables* dt;
+  uint64_t nsub;       // 512-bit subsequences covering the body
+  uint16_t* start;     // [nsub + 1] current guess: bit offset of the first code boundary inside each subsequence
+  uint16_t* used;      // [nsub]     the guess the stored result was computed from (0xFFFF = none yet)
+  uint32_t* cnt;       // [nsub]     codes starting in the subsequence (up to an end mark)
+  uint8_t* eof;        // [nsub]     the end mark was decoded in this subsequence
+  uint32_t* changed;   // some guess moved during the pass
+  uint64_t* eof_sub;   // first subsequence holding the end mark
+  uint64_t* tile_sum;  // [nsub / 256 + 2] symbols per tile, then (in place) their exclusive scan
+};
+
 // kernel launchers (ghf_kernels.hip); all asynchronous on `s`
+void launch_sync_pass(const SyncParams& p, hipStream_t s);
+void launch_sync_counts(const SyncParams& p, uint64_t* d_total, hipStream_t s);
+void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_segs, uint32_t chunk_log2, uint64_t* d_chunk_bit,
+                       uint32_t* d_seg_bit, hipStream_t s);
 void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, uint32_t* d_chunk_hist,
                       uint64_t* d_hist, hipStream_t s);
 void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, hipStream_t s);

@@ -67,45 +67,11 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
   uint32_t prev = 0;
   unsigned long long total = 0;
   const uint64_t chunk = 1ull << chunk_log2;
-  for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    const uint64_t base = (uint64_t)c << chunk_log2;
-    const uint64_t len = (n - base < chunk) ? (n - base) : chunk;
-    const uint8_t* p = in + base;
-    uint32_t head = (uint32_t)((16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
-    if (head > len) head = (uint32_t)len;
-    if (tid < head) atomicAdd(&lh[((uint32_t)p[tid] << 5) | rep], 1u);
-    const uint4* pv = reinterpret_cast<const uint4*>(p + head);
-    const uint64_t nvec = (len - head) >> 4;
-    uint64_t i = tid;
-    // software pipeline without register moves: while A/B are counted, C/D are in flight and vice versa
-    // (every load instruction is a fully coalesced 1 KiB per wave)
-    constexpr uint64_t S = kHistThreads;
-    if (i + 3 * S < nvec) {
-      uint4 A = pv[i], B = pv[i + S];
-      for (; i + 7 * S < nvec; i += 4 * S) {
-        const uint4 C = pv[i + 2 * S], D = pv[i + 3 * S];
-        hist_vec(lh, rep, A);
-        hist_vec(lh, rep, B);
-        A = pv[i + 4 * S];
-        B = pv[i + 5 * S];
-        hist_vec(lh, rep, C);
-        hist_vec(lh, rep, D);
-      }
-      const uint4 C = pv[i + 2 * S], D = pv[i + 3 * S];
-      hist_vec(lh, rep, A);
-      hist_vec(lh, rep, B);
-      hist_vec(lh, rep, C);
-      hist_vec(lh, rep, D);
-      i += 4 * S;
-    }
-    for (; i < nvec; i += S) {
-      const uint4 v0 = pv[i];
-      hist_vec(lh, rep, v0);
-    }
-    const uint64_t tail0 = head + (nvec << 4);
-    if (tail0 + tid < len) atomicAdd(&lh[((uint32_t)p[tail0 + tid] << 5) | rep], 1u);
+
+  // end of a chunk: thread t sums the 32 replicas of bin t (rotated start: 32 lanes on 32 banks); the counters
+  // keep running, the chunk's count is the difference to the previous sum (mod 2^32)
+  auto finish_chunk = [&](uint32_t c) {
     __syncthreads();
-    // thread t sums the 32 replicas of bin t; rotated start keeps the 32 lanes on 32 banks
     uint32_t s = 0;
 #pragma unroll
     for (uint32_t j = 0; j < kHistRep; ++j) s += lh[(tid << 5) | ((j + tid) & 31u)];
@@ -114,6 +80,54 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
     chunk_hist[(uint64_t)c * 256 + tid] = cnt;
     total += cnt;
     __syncthreads();
+  };
+
+  // ---- fast phase: this workgroup's full, 16-byte aligned chunks as ONE stream of 16-byte vectors per thread.
+  // Four loads per lane are always in flight (A/B and C/D alternate, no register copies), including across the
+  // chunk boundary: the first vectors of the next chunk are already requested while this chunk is being reduced.
+  const uint32_t vlog = chunk_log2 - 12;  // vectors per thread per chunk = 2^vlog (256 threads x 16 B = 4 KiB)
+  const uint32_t nfullchunks = (uint32_t)(n >> chunk_log2);
+  uint32_t mdone = 0;  // how many of this workgroup's chunks the fast phase covered
+  if (vlog >= 2 && (((uintptr_t)in) & 15u) == 0 && blockIdx.x < nfullchunks) {
+    const uint32_t mfull = (nfullchunks - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const uint64_t F = (uint64_t)mfull << vlog;
+    const uint64_t vmask = (1ull << vlog) - 1;
+    auto vptr = [&](uint64_t f) -> const uint4* {
+      if (f >= F) f = F - 1;  // clamped: the very last prefetches are redundant, never out of bounds
+      const uint64_t c = blockIdx.x + (f >> vlog) * gridDim.x;
+      return reinterpret_cast<const uint4*>(in + (c << chunk_log2)) + (f & vmask) * kHistThreads + tid;
+    };
+    uint4 A = *vptr(0), B = *vptr(1);
+    for (uint64_t f = 0; f < F; f += 4) {
+      const uint4 C = *vptr(f + 2), D = *vptr(f + 3);
+      hist_vec(lh, rep, A);
+      hist_vec(lh, rep, B);
+      A = *vptr(f + 4);
+      B = *vptr(f + 5);
+      hist_vec(lh, rep, C);
+      hist_vec(lh, rep, D);
+      if (((f + 4) & vmask) == 0) finish_chunk(blockIdx.x + (uint32_t)(f >> vlog) * gridDim.x);
+    }
+    mdone = mfull;
+  }
+
+  // ---- generic phase: small chunks, unaligned input, the ragged last chunk
+  for (uint32_t c = blockIdx.x + mdone * gridDim.x; c < nchunks; c += gridDim.x) {
+    const uint64_t base = (uint64_t)c << chunk_log2;
+    const uint64_t len = (n - base < chunk) ? (n - base) : chunk;
+    const uint8_t* p = in + base;
+    uint32_t head = (uint32_t)((16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
+    if (head > len) head = (uint32_t)len;
+    if (tid < head) atomicAdd(&lh[((uint32_t)p[tid] << 5) | rep], 1u);
+    const uint4* pv = reinterpret_cast<const uint4*>(p + head);
+    const uint64_t nvec = (len - head) >> 4;
+    for (uint64_t i = tid; i < nvec; i += kHistThreads) {
+      const uint4 v0 = pv[i];
+      hist_vec(lh, rep, v0);
+    }
+    const uint64_t tail0 = head + (nvec << 4);
+    if (tail0 + tid < len) atomicAdd(&lh[((uint32_t)p[tail0 + tid] << 5) | rep], 1u);
+    finish_chunk(c);
   }
   if (total) atomicAdd(&hist[tid], total);
   if (blockIdx.x == 0 && tid == 0) hist[256] = 1;  // include/encoder.h:128 end-of-stream mark counts once
@@ -122,7 +136,18 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
 void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, uint32_t* d_chunk_hist,
                       uint64_t* d_hist, hipStream_t s) {
   (void)hipMemsetAsync(d_hist, 0, GHF_NSYM * sizeof(uint64_t), s);
-  uint32_t grid = nchunks < 1280u ? nchunks : 1280u;  // 5 x 32 KiB LDS per CU
+  // exactly one resident wave of workgroups (registers allow 4 per CU, LDS 5): a grid one notch larger would run
+  // as a full round plus a nearly empty one
+  static int per_cu = 0, ncu = 0;
+  if (per_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_histogram, kHistThreads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (ncu < 1) ncu = 256;
+  }
+  uint32_t grid = (uint32_t)(per_cu * ncu);
+  if (grid > nchunks) grid = nchunks;
   if (grid == 0) grid = 1;
   hipLaunchKernelGGL(k_histogram, dim3(grid), dim3(kHistThreads), 0, s, d_in, n, chunk_log2, nchunks, d_chunk_hist,
                      reinterpret_cast<unsigned long long*>(d_hist));
@@ -486,11 +511,11 @@ void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t 
 //   last unit of a chunk are shared with a neighbouring chunk: those are OR-ed into pre-zeroed
 //   memory (k_emit_prep).  No workgroup barrier after the table is built.
 // ------------------------------------------------------------------------------------------------
-struct E32 {  // codes <= 24 bits
+struct E32 {  // table entry for codes <= 24 bits: code << 8 | len
   typedef uint32_t T;
-  static __device__ __forceinline__ T make(uint32_t code, uint32_t len) { return (len << 24) | code; }
-  static __device__ __forceinline__ uint32_t len(T e) { return e >> 24; }
-  static __device__ __forceinline__ uint32_t code(T e) { return e & 0xFFFFFFu; }
+  static __device__ __forceinline__ T make(uint32_t code, uint32_t len) { return (code << 8) | len; }
+  static __device__ __forceinline__ uint32_t len(T e) { return e & 0xFFu; }
+  static __device__ __forceinline__ uint32_t code(T e) { return e >> 8; }
   static __device__ __forceinline__ uint32_t slot(uint32_t byte, uint32_t lane) { return (byte << 5) | (lane & 31u); }
   static constexpr uint32_t kRep = 32;
 };
@@ -503,11 +528,61 @@ struct E64 {  // codes up to 32 bits
   static constexpr uint32_t kRep = 16;
 };
 
+// Three variants of the same kernel, picked by max_len (device side: the host cannot know it without a round trip):
+//   PairMode  max_len <= 16 : two neighbouring symbols are fused into one <= 32-bit item right after the table
+//                             lookup, which halves the serial work of the bit packer (every BASELINE config)
+//   MidMode   17..24        : one item per symbol, 32-bit table entries
+//   WideMode  25..32        : one item per symbol, 64-bit table entries
+struct PairMode {
+  typedef E32 E;
+  static constexpr int N = 8;
+  static constexpr int kMinWaves = 4;
+  static __device__ __forceinline__ bool applies(int max_len) { return max_len <= 16; }
+};
+struct MidMode {
+  typedef E32 E;
+  static constexpr int N = 16;
+  static constexpr int kMinWaves = 4;
+  static __device__ __forceinline__ bool applies(int max_len) { return max_len > 16 && max_len <= 24; }
+};
+struct WideMode {
+  typedef E64 E;
+  static constexpr int N = 16;
+  static constexpr int kMinWaves = 4;
+  static __device__ __forceinline__ bool applies(int max_len) { return max_len > 24; }
+};
+
+template <int N>
+struct Items {  // what one lane appends in one iteration: N (code, length <= 32) pairs, in stream order
+  uint32_t code[N];
+  uint32_t len[N];
+};
+
+template <typename M>
+__device__ __forceinline__ void make_items(const typename M::E::T (&e)[16], Items<M::N>& it) {
+  typedef typename M::E E;
+  if (M::N == 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      it.code[j & (M::N - 1)] = E::code(e[j]);
+      it.len[j & (M::N - 1)] = E::len(e[j]);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint32_t l1 = E::len(e[2 * p + 1]);
+      it.code[p & (M::N - 1)] = (E::code(e[2 * p]) << l1) | E::code(e[2 * p + 1]);
+      it.len[p & (M::N - 1)] = E::len(e[2 * p]) + l1;
+    }
+  }
+}
+
 struct WaveOut {
   uint32_t* st;         // this wave's LDS staging words
   uint4* out_units;     // output as 16-byte units
   uint64_t unit_base;   // unit index (in out) of staging unit 0
   uint32_t carry;       // valid bits at the front of the staging area (< 128)
+  uint32_t cw;          // the staging word holding the last carried bits (top carry%32 bits valid, rest zero)
   bool first_pending;   // the chunk's first unit has not been written yet -> it is shared -> OR it in
 };
 
@@ -518,18 +593,15 @@ __device__ __forceinline__ void or_unit_words(uint4* unit, const uint32_t* st4, 
   }
 }
 
-// pack this lane's 16 entries at staging bit `sb`; lanes with active == false do nothing.
-// pass_total = bits of all active lanes; first = lowest active lane.
-template <typename E>
-__device__ __forceinline__ void pack_pass(WaveOut& W, const typename E::T (&e)[16], bool active, uint32_t sb,
-                                          uint32_t pass_total, bool is_first_lane, int lane) {
+// pack this lane's items at staging bit `sb`; lanes with active == false do nothing.
+// pass_total = bits of all active lanes; is_first_lane marks the lowest active lane.
+template <int N>
+__device__ __forceinline__ void pack_pass(WaveOut& W, const Items<N>& it, bool active, uint32_t sb, uint32_t pass_total,
+                                          bool is_first_lane, int lane) {
   uint32_t* st = W.st;
   uint32_t w = sb >> 5;
   uint32_t nb = sb & 31u;
   uint64_t acc = 0;
-  // the first lane continues the carried partial word
-  if (is_first_lane && nb) acc = (uint64_t)(st[w] >> (32u - nb));
-  wave_sync();
   // the word that will only receive OR-ed residuals (and the rest of its unit) must start as zero
   if (is_first_lane) {
     const uint32_t wpart = (W.carry + pass_total) >> 5;
@@ -538,9 +610,9 @@ __device__ __forceinline__ void pack_pass(WaveOut& W, const typename E::T (&e)[1
   wave_sync();
   if (active) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint32_t l = E::len(e[j]);
-      acc = (acc << l) | E::code(e[j]);
+    for (int j = 0; j < N; ++j) {
+      const uint32_t l = it.len[j];
+      acc = (acc << l) | it.code[j];
       nb += l;
       if (nb >= 32u) {
         nb -= 32u;
@@ -550,6 +622,9 @@ __device__ __forceinline__ void pack_pass(WaveOut& W, const typename E::T (&e)[1
   }
   wave_sync();
   if (active && nb) atomicOr(&st[w], ((uint32_t)acc) << (32u - nb));
+  // the first lane's first word was stored with zeros where the carried bits of the previous pass were (or was
+  // just cleared above): put them back.  W.cw was read at the end of the previous pass, so nobody waits for it.
+  if (is_first_lane && (sb & 31u)) atomicOr(&st[sb >> 5], W.cw);
   wave_sync();
   // write the completed 16-byte units, carry the incomplete one
   const uint32_t endbits = W.carry + pass_total;
@@ -579,15 +654,16 @@ __device__ __forceinline__ void pack_pass(WaveOut& W, const typename E::T (&e)[1
   }
   W.carry = endbits & 127u;
   wave_sync();
+  W.cw = st[W.carry >> 5];
 }
 
-// one wave iteration: 16 table entries per lane -> bits in the staging area -> whole units to HBM
-template <typename E>
-__device__ __forceinline__ void emit_iteration(WaveOut& W, const typename E::T (&e)[16], int lane, uint32_t* seg_out,
-                                               uint64_t relbits, bool seg_valid, uint32_t& total_out) {
+// one wave iteration: items of every lane -> bits in the staging area -> whole units to HBM
+template <int N>
+__device__ __forceinline__ void emit_iteration(WaveOut& W, const Items<N>& it, int lane, uint32_t* seg_out, uint64_t relbits,
+                                               bool seg_valid, uint32_t& total_out) {
   uint32_t T = 0;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) T += E::len(e[j]);
+  for (int j = 0; j < N; ++j) T += it.len[j];
   const uint32_t incl = wave_incl_scan_u32(T, lane);
   const uint32_t excl = incl - T;
   const uint32_t total = __shfl(incl, 63, 64);
@@ -603,7 +679,7 @@ __device__ __forceinline__ void emit_iteration(WaveOut& W, const typename E::T (
     const bool active = !split || ((lane >= 32) == second);
     const uint32_t base = second ? half_total : 0u;
     const uint32_t ptotal = split ? (second ? total - half_total : half_total) : total;
-    pack_pass<E>(W, e, active, W.carry + (excl - base), ptotal, lane == (second ? 32 : 0), lane);
+    pack_pass<N>(W, it, active, W.carry + (excl - base), ptotal, lane == (second ? 32 : 0), lane);
   }
 }
 
@@ -617,9 +693,10 @@ __device__ __forceinline__ void lookup16(const typename E::T* tab, const uint4& 
   }
 }
 
-template <typename E>
-__device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, const typename E::T* tab, uint32_t* st,
+template <typename M>
+__device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, const typename M::E::T* tab, uint32_t* st,
                                            uint64_t start_bit, uint64_t origin_byte, int lane) {
+  typedef typename M::E E;
   typedef typename E::T ET;
   const uint64_t chunk = 1ull << P.chunk_log2;
   const uint64_t sym0 = (uint64_t)c << P.chunk_log2;
@@ -632,6 +709,7 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, cons
   W.out_units = reinterpret_cast<uint4*>(P.out);
   W.unit_base = (Pc >> 7) - (origin_byte >> 4);
   W.carry = (uint32_t)(Pc & 127u);
+  W.cw = 0;
   W.first_pending = true;
   if (lane < 8) st[lane] = 0;
   if (lane == 0 && P.chunk_bit) P.chunk_bit[c] = Pc - origin_byte * 8;  // relative to d_out[0]
@@ -653,8 +731,10 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, cons
         A = pv[nx * 64];
         ET e[16];
         lookup16<E>(tab, v, lane, e);
+        Items<M::N> items;
+        make_items<M>(e, items);
         uint32_t total;
-        emit_iteration<E>(W, e, lane, segp ? segp + it * 16 : nullptr, relbits, true, total);
+        emit_iteration<M::N>(W, items, lane, segp ? segp + it * 16 : nullptr, relbits, true, total);
         relbits += total;
       }
       {
@@ -663,8 +743,10 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, cons
         B = pv[nx * 64];
         ET e[16];
         lookup16<E>(tab, v, lane, e);
+        Items<M::N> items;
+        make_items<M>(e, items);
         uint32_t total;
-        emit_iteration<E>(W, e, lane, segp ? segp + (it + 1) * 16 : nullptr, relbits, true, total);
+        emit_iteration<M::N>(W, items, lane, segp ? segp + (it + 1) * 16 : nullptr, relbits, true, total);
         relbits += total;
       }
     }
@@ -675,7 +757,7 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, cons
   const bool last = (P.flags & GHF_EMIT_LAST) && c + 1 == P.nchunks;
   const uint64_t nsteps = niter + (last ? 1 : 0);
   for (; it < nsteps; ++it) {
-    ET e[16];
+    Items<M::N> items;
     bool seg_valid = false;
     uint32_t* seg_out = nullptr;
     if (it < niter) {
@@ -692,34 +774,43 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, cons
         for (uint32_t j = 0; j < cnt; ++j) q[j >> 2] |= (uint32_t)pin[sb + lo + j] << (8 * (j & 3));
         v = make_uint4(q[0], q[1], q[2], q[3]);
       }
+      ET e[16];
       lookup16<E>(tab, v, lane, e);
       if (cnt < 16) {
 #pragma unroll
         for (int j = 0; j < 16; ++j)
           if ((uint32_t)j >= cnt) e[j] = 0;
       }
+      make_items<M>(e, items);
       seg_valid = cnt != 0;
       seg_out = segp ? segp + it * 16 : nullptr;
     } else {
       const uint32_t el = P.code->length[GHF_NSYM - 1], ec = P.code->codeword[GHF_NSYM - 1];
       const uint32_t pad = (uint32_t)((0 - (Pc + relbits + el)) & 7u);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) e[j] = 0;
+      for (int j = 0; j < M::N; ++j) {
+        items.code[j] = 0;
+        items.len[j] = 0;
+      }
       if (lane == 0) {
-        e[0] = E::make(ec, el);
-        e[1] = E::make((1u << pad) - 1u, pad);
+        items.code[0] = ec;
+        items.len[0] = el;
+        items.code[1] = (1u << pad) - 1u;
+        items.len[1] = pad;
       }
     }
     uint32_t total;
-    emit_iteration<E>(W, e, lane, seg_out, relbits, seg_valid, total);
+    emit_iteration<M::N>(W, items, lane, seg_out, relbits, seg_valid, total);
     relbits += total;
   }
   // the chunk's last, incomplete unit is shared with the next chunk (or is the end of the stream)
   if (W.carry) or_unit_words(W.out_units + W.unit_base, st, lane);
 }
 
-__global__ __launch_bounds__(kEmitThreads) void k_emit(EmitParams P) {
-  __shared__ __attribute__((aligned(16))) uint64_t tab_raw[256 * 16];  // 32 KiB: [256][32] u32 or [256][16] u64
+template <typename M>
+__global__ __launch_bounds__(kEmitThreads, M::kMinWaves) void k_emit(EmitParams P) {
+  typedef typename M::E E;
+  __shared__ __attribute__((aligned(16))) typename E::T tab[256 * E::kRep];  // 32 KiB: [256][32] u32 or [256][16] u64
   __shared__ __attribute__((aligned(16))) uint32_t stage[kEmitWaves][kStageWords];
   __shared__ int status0;
   const int tid = threadIdx.x;
@@ -727,18 +818,10 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EmitParams P) {
   __syncthreads();
   if (status0 != 0) return;
   const int max_len = P.code->max_len;
-  const bool wide = max_len > 24;
-  if (!wide) {
-    uint32_t* t32 = reinterpret_cast<uint32_t*>(tab_raw);
-    for (int i = tid; i < 256 * 32; i += kEmitThreads) {
-      const int s = i >> 5;
-      t32[i] = E32::make(P.code->codeword[s], P.code->length[s]);
-    }
-  } else {
-    for (int i = tid; i < 256 * 16; i += kEmitThreads) {
-      const int s = i >> 4;
-      tab_raw[i] = E64::make(P.code->codeword[s], P.code->length[s]);
-    }
+  if (!M::applies(max_len)) return;
+  for (int i = tid; i < 256 * (int)E::kRep; i += kEmitThreads) {
+    const int s = i / (int)E::kRep;
+    tab[i] = E::make(P.code->codeword[s], P.code->length[s]);
   }
   __syncthreads();
   const int lane = tid & 63;
@@ -747,10 +830,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(EmitParams P) {
   if (c >= P.nchunks) return;
   const uint64_t start_bit = P.d_start_bit ? *P.d_start_bit : 8ull * (1040ull + 8ull * (uint64_t)max_len);
   const uint64_t origin_byte = (P.flags & GHF_EMIT_REBASE) ? ((start_bit >> 7) << 4) : 0ull;
-  if (!wide)
-    emit_chunk<E32>(P, c, reinterpret_cast<const uint32_t*>(tab_raw), stage[wave], start_bit, origin_byte, lane);
-  else
-    emit_chunk<E64>(P, c, tab_raw, stage[wave], start_bit, origin_byte, lane);
+  emit_chunk<M>(P, c, tab, stage[wave], start_bit, origin_byte, lane);
 }
 
 // zero the 16-byte units two chunks share, check the capacity, report where the stream ends
@@ -803,7 +883,9 @@ void launch_emit(const EmitParams& p, hipStream_t s) {
   const uint32_t prep_blocks = (p.nchunks + 1 + 255) / 256;
   hipLaunchKernelGGL(k_emit_prep, dim3(prep_blocks), dim3(256), 0, s, p);
   const uint32_t blocks = (p.nchunks + kEmitWaves - 1) / kEmitWaves;
-  hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(kEmitThreads), 0, s, p);
+  hipLaunchKernelGGL(k_emit<PairMode>, dim3(blocks), dim3(kEmitThreads), 0, s, p);
+  hipLaunchKernelGGL(k_emit<MidMode>, dim3(blocks), dim3(kEmitThreads), 0, s, p);
+  hipLaunchKernelGGL(k_emit<WideMode>, dim3(blocks), dim3(kEmitThreads), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1074,6 +1156,246 @@ void launch_decode(const DecParams& p, hipStream_t s) {
   if (blocks == 0) return;
   if (blocks > 256 * 5) blocks = 256 * 5;  // persistent: 5 workgroups per CU fit the LDS
   hipLaunchKernelGGL(k_decode, dim3((uint32_t)blocks), dim3(kDecThreads), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: rebuild the side-car of a FOREIGN stream (a .crs2 written by the reference has no sync points).
+// Huffman codes self-synchronise: a decoder started at a wrong bit falls into step with the true
+// code boundaries after a few symbols.  The body is cut into 512-bit subsequences; every thread decodes
+// its subsequence from its current guess of the first code boundary and tells its right neighbour where
+// it landed.  Thread 0 starts at a true boundary, so the fixed point of this iteration is the true
+// segmentation; passes repeat (only threads whose guess changed redo work) until nothing changes.
+// Then symbol counts are prefix-summed, the end mark fixes n, and one more pass writes the bit position
+// of every 64th symbol -- the same side-car K5 emits.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSubBits = 512;
+
+struct BitReader {  // left-justified 64-bit window over big-endian words (LDS)
+  const uint32_t* in;
+  uint32_t widx;
+  uint64_t window;
+  int avail;
+  __device__ __forceinline__ void init(const uint32_t* words, uint64_t pos) {
+    in = words;
+    widx = (uint32_t)(pos >> 5);
+    const uint32_t off = (uint32_t)(pos & 31u);
+    window = (((uint64_t)in[widx] << 32) | in[widx + 1]) << off;
+    widx += 2;
+    avail = 64 - (int)off;
+  }
+  __device__ __forceinline__ uint32_t hi() {
+    if (avail < 32) {
+      window |= (uint64_t)in[widx++] << (32 - avail);
+      avail += 32;
+    }
+    return (uint32_t)(window >> 32);
+  }
+  __device__ __forceinline__ void skip(uint32_t len) {
+    window <<= len;
+    avail -= (int)len;
+  }
+};
+
+__device__ __forceinline__ uint32_t dec_any(const DecLds& L, uint32_t hi, int lut_bits, int max_len, uint32_t& len) {
+  const uint32_t ent = L.lut[hi >> (32 - lut_bits)];
+  len = ent >> 9;
+  if (len) return ent & 0x1FFu;
+  const uint32_t r = dec_long(L, hi, lut_bits, max_len);
+  len = r >> 16;
+  return r & 0xFFFFu;
+}
+
+__device__ __forceinline__ void dec_lds_load(DecLds& L, const DecTables* dt, int tid, int nthreads) {
+  const int lut_bits = dt->lut_bits;
+  const uint4* src = reinterpret_cast<const uint4*>(dt->lut);
+  uint4* dst = reinterpret_cast<uint4*>(L.lut);
+  for (int i = tid; i < ((1 << lut_bits) * 2 + 15) / 16; i += nthreads) dst[i] = src[i];
+  if (tid < 36) {
+    L.fcl[tid] = dt->fc_left[tid];
+    L.sp[tid] = dt->start_pos[tid];
+  }
+  for (int i = tid; i < GHF_NSYM; i += nthreads) L.symbol[i] = dt->symbol[i];
+}
+
+// stage the bits of 64 consecutive subsequences (+ look-ahead) of the body into this wave's LDS words;
+// returns the bit offset of subsequence `sub0` inside the staged words
+__device__ __forceinline__ uint64_t stage_subs(const SyncParams& P, uint64_t sub0, uint32_t* in, int lane) {
+  const uint64_t bit0 = P.body_bit0 + sub0 * kSubBits;
+  const uint64_t byte0 = (bit0 >> 3) & ~15ull;
+  uint64_t byte1 = ((bit0 + 64ull * kSubBits + 7) >> 3) + 16;
+  if (byte1 > P.stream_bytes) byte1 = P.stream_bytes;
+  const uint64_t span = byte1 > byte0 ? byte1 - byte0 : 0;
+  const uint8_t* src = P.stream + byte0;
+  for (uint64_t o = (uint64_t)lane * 16; o < span; o += 1024) {
+    uint4 v;
+    if (o + 16 <= span) {
+      v = *reinterpret_cast<const uint4*>(src + o);
+    } else {
+      uint32_t q[4] = {0, 0, 0, 0};
+      for (uint32_t j = 0; o + j < span; ++j) q[j >> 2] |= (uint32_t)src[o + j] << (8 * (j & 3));
+      v = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+    *reinterpret_cast<uint4*>(in + (o >> 2)) = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+  }
+  const uint32_t wend = (uint32_t)((span + 15) >> 4) << 2;
+  for (uint32_t k = wend + lane; k < (uint32_t)kDecInWords + 4; k += 64) in[k] = 0;
+  return bit0 - byte0 * 8;
+}
+
+__global__ __launch_bounds__(kDecThreads) void k_sync_pass(SyncParams P) {
+  __shared__ DecLds L;
+  const int tid = threadIdx.x;
+  dec_lds_load(L, P.dt, tid, kDecThreads);
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
+  const uint64_t ngroups = (P.nsub + 63) >> 6;
+  const uint64_t body_bits = P.stream_bytes * 8 - P.body_bit0;
+  uint32_t* in = L.in[wave];
+  for (uint64_t g = (uint64_t)blockIdx.x * kDecWaves + wave; g < ngroups; g += (uint64_t)gridDim.x * kDecWaves) {
+    const uint64_t sub = g * 64 + lane;
+    const bool valid = sub < P.nsub;
+    uint32_t st = 0;
+    bool work = false;
+    if (valid) {
+      st = P.start[sub];
+      work = P.used[sub] != st;
+    }
+    if (!__ballot(work)) continue;  // the whole wave's results are still current
+    wave_sync();
+    const uint64_t base = stage_subs(P, g * 64, in, lane);
+    wave_sync();
+    if (work) {
+      const uint64_t sub_lo = (uint64_t)lane * kSubBits;  // relative to the wave's first subsequence
+      const uint64_t sub_hi = sub_lo + kSubBits;
+      const uint64_t limit = body_bits - g * 64 * kSubBits;  // end of the stream, same origin
+      uint64_t pos = sub_lo + st;
+      uint32_t count = 0;
+      bool eof = false;
+      BitReader br;
+      br.init(in, base + pos);
+      while (pos < sub_hi && pos < limit) {
+        uint32_t len;
+        const uint32_t sym = dec_any(L, br.hi(), lut_bits, max_len, len);
+        if (sym == 256u) {
+          eof = true;
+          break;
+        }
+        br.skip(len);
+        pos += len;
+        ++count;
+      }
+      P.cnt[sub] = count;
+      P.eof[sub] = eof ? 1 : 0;
+      P.used[sub] = (uint16_t)st;
+      if (!eof && pos >= sub_hi && sub + 1 < P.nsub) {
+        const uint16_t land = (uint16_t)(pos - sub_hi);
+        if (P.start[sub + 1] != land) {
+          P.start[sub + 1] = land;
+          *P.changed = 1;
+        }
+      }
+    }
+  }
+}
+
+// first subsequence that holds the end mark (valid once the passes have converged)
+__global__ __launch_bounds__(256) void k_sync_eof(SyncParams P) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < P.nsub && P.eof[i]) atomicMin(reinterpret_cast<unsigned long long*>(P.eof_sub), (unsigned long long)i);
+}
+
+// symbols per tile of 256 subsequences, nothing counted behind the end mark
+__global__ __launch_bounds__(256) void k_sync_tile_sums(SyncParams P) {
+  __shared__ unsigned long long ws[4];
+  const uint64_t eof_sub = *P.eof_sub;
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long v = (i < P.nsub && i <= eof_sub) ? P.cnt[i] : 0ull;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) P.tile_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// absolute bit position of every 64th symbol (the side-car's granularity)
+__global__ __launch_bounds__(kDecThreads) void k_sync_index(SyncParams P, uint64_t* __restrict__ seg_abs, uint64_t n_segs) {
+  __shared__ DecLds L;
+  __shared__ unsigned long long wsum[kDecWaves];
+  const int tid = threadIdx.x;
+  dec_lds_load(L, P.dt, tid, kDecThreads);
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
+  const uint64_t eof_sub = *P.eof_sub;
+  const uint64_t sub = (uint64_t)blockIdx.x * 256 + tid;  // one tile of 256 subsequences per workgroup
+  const bool valid = sub < P.nsub && sub <= eof_sub;
+  const uint32_t c = valid ? P.cnt[sub] : 0u;
+  // exclusive prefix of the symbol counts inside the tile
+  unsigned long long incl = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned long long first = P.tile_sum[blockIdx.x] + incl - c;  // tile_sum[] holds the exclusive scan by now
+  for (int k = 0; k < wave; ++k) first += wsum[k];
+  const uint64_t g = (uint64_t)blockIdx.x * kDecWaves + wave;
+  uint32_t* in = L.in[wave];
+  if (g * 64 >= P.nsub) return;
+  const uint64_t base = stage_subs(P, g * 64, in, lane);
+  wave_sync();
+  if (!valid) return;
+  const uint64_t body_bits = P.stream_bytes * 8 - P.body_bit0;
+  const uint64_t sub_lo = (uint64_t)lane * kSubBits;
+  const uint64_t limit = body_bits - g * 64 * kSubBits;
+  uint64_t pos = sub_lo + P.start[sub];
+  BitReader br;
+  br.init(in, base + pos);
+  const uint64_t abs0 = P.body_bit0 + g * 64 * kSubBits;  // stream bit of the wave's first subsequence
+  for (uint32_t k = 0; k < c && pos < limit; ++k) {
+    const uint64_t sidx = first + k;
+    if ((sidx & 63u) == 0 && (sidx >> 6) < n_segs) seg_abs[sidx >> 6] = abs0 + pos;
+    uint32_t len;
+    (void)dec_any(L, br.hi(), lut_bits, max_len, len);
+    br.skip(len);
+    pos += len;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sync_finalize(const uint64_t* __restrict__ seg_abs, uint64_t n_segs, uint32_t chunk_log2,
+                                                       uint64_t* __restrict__ chunk_bit, uint32_t* __restrict__ seg_bit) {
+  const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_segs) return;
+  const uint64_t c = (s * kSegSymbols) >> chunk_log2;
+  const uint64_t s0 = (c << chunk_log2) / kSegSymbols;
+  const uint64_t b0 = seg_abs[s0];
+  if (s == s0) chunk_bit[c] = b0;
+  seg_bit[s] = (uint32_t)(seg_abs[s] - b0);
+}
+
+void launch_sync_pass(const SyncParams& p, hipStream_t s) {
+  const uint64_t groups = (p.nsub + 63) / 64;
+  uint64_t blocks = (groups + kDecWaves - 1) / kDecWaves;
+  if (blocks > 256 * 5) blocks = 256 * 5;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_sync_pass, dim3((uint32_t)blocks), dim3(kDecThreads), 0, s, p);
+}
+void launch_sync_counts(const SyncParams& p, uint64_t* d_total, hipStream_t s) {
+  const uint32_t tiles = (uint32_t)((p.nsub + 255) / 256);
+  hipLaunchKernelGGL(k_sync_eof, dim3(tiles), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_sync_tile_sums, dim3(tiles), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, p.tile_sum, tiles, d_total);
+}
+void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_segs, uint32_t chunk_log2, uint64_t* d_chunk_bit,
+                       uint32_t* d_seg_bit, hipStream_t s) {
+  const uint32_t tiles = (uint32_t)((p.nsub + 255) / 256);
+  hipLaunchKernelGGL(k_sync_index, dim3(tiles), dim3(kDecThreads), 0, s, p, d_seg_abs, n_segs);
+  if (n_segs) hipLaunchKernelGGL(k_sync_finalize, dim3((uint32_t)((n_segs + 255) / 256)), dim3(256), 0, s, d_seg_abs, n_segs,
+                                 chunk_log2, d_chunk_bit, d_seg_bit);
 }
 
 // *dst = (src ? *src : 0) + add   (tiny device-side bookkeeping without a host round trip)

@@ -260,9 +260,10 @@ class Context:
             "ghf_compress")
         return d_out, nbytes, d_code
 
-    def decode(self, d_stream, stream_bytes, d_code, index, d_out=None):
+    def decode(self, d_stream, stream_bytes, d_code, index=None, d_out=None, cap=None):
+        """index=None: a stream without side-car (e.g. written by the reference); the library rebuilds it on the GPU."""
         if d_out is None:
-            d_out = self.empty_u8(index.n_symbols)
+            d_out = self.empty_u8(index.n_symbols if index is not None else cap)
         nbytes = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
         self._chk(
             self.L.ghf_decode(self.h, d_stream.data_ptr(), stream_bytes, d_code.data_ptr(),

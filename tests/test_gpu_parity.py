@@ -154,6 +154,51 @@ def test_error_statuses(env):
     assert np.array_equal(d_out[: int(nbytes.item())].cpu().numpy(), orc.compress(data))
 
 
+FOREIGN = ["aaaabbc", "single_x", "all256_once", "uniform_64k", "zipf_64k", "sym16_64k", "fib22", "fib32_maxlen32", "geom16",
+           "text_1m", "zeros_100000", "uniform_65537", "zipf_n3007", "two_values_skewed"]
+
+
+@pytest.mark.parametrize("name", FOREIGN)
+def test_foreign_stream_without_sidecar(env, name):
+    """a .crs2 as the reference writes it (here: the oracle, byte-identical to it) decodes with no side-car:
+    the library re-synchronises on the GPU (K6) and then runs the same table decode."""
+    ghf, ctx, torch = env
+    data = CASES[name]()
+    crs = orc.compress(data)
+    code, hs = ghf.parse_header(crs)
+    d_stream = to_dev(torch, np.concatenate([crs, np.zeros(64, np.uint8)]))
+    d_code = ctx.code_to_device(code)
+    out, nout = ctx.decode(d_stream, crs.size, d_code, None, cap=data.size + 64)
+    ctx.sync()
+    assert int(nout.item()) == data.size
+    assert np.array_equal(out[: data.size].cpu().numpy(), data)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf", "sym16"])
+def test_foreign_stream_16MiB(env, kind):
+    ghf, ctx, torch = env
+    n = (1 << 24) + 77
+    data = dg.make(kind, n, seed=321)
+    crs = orc.compress(data)
+    code, hs = ghf.parse_header(crs)
+    d_stream = to_dev(torch, crs)
+    out, nout = ctx.decode(d_stream, crs.size, ctx.code_to_device(code), None, cap=n + 4096)
+    ctx.sync()
+    assert int(nout.item()) == n
+    assert np.array_equal(out[:n].cpu().numpy(), data)
+
+
+def test_foreign_stream_truncated_is_reported(env):
+    ghf, ctx, torch = env
+    data = dg.zipf_bytes(100000, seed=4)
+    crs = orc.compress(data)
+    code, hs = ghf.parse_header(crs)
+    cut = crs[: crs.size - 2000].copy()
+    with pytest.raises(ghf.GhfError):
+        ctx.decode(to_dev(torch, cut), cut.size, ctx.code_to_device(code), None, cap=data.size + 64)
+        ctx.sync()
+
+
 def test_decode_detects_corruption(env):
     ghf, ctx, torch = env
     data = dg.zipf_bytes(500000, seed=17)
