@@ -136,17 +136,16 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
 void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, uint32_t* d_chunk_hist,
                       uint64_t* d_hist, hipStream_t s) {
   (void)hipMemsetAsync(d_hist, 0, GHF_NSYM * sizeof(uint64_t), s);
-  // exactly one resident wave of workgroups (registers allow 4 per CU, LDS 5): a grid one notch larger would run
-  // as a full round plus a nearly empty one
-  static int per_cu = 0, ncu = 0;
-  if (per_cu == 0) {
+  // one resident round of workgroups, 4 per CU: measured faster than the 5 the LDS would allow (2 GiB stream:
+  // 5.55 TB/s at 1024 workgroups vs 4.95 TB/s at 1280 -- the fifth workgroup only adds L2/LDS pressure)
+  static int ncu = 0;
+  if (ncu == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_histogram, kHistThreads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (ncu < 1) ncu = 256;
   }
-  uint32_t grid = (uint32_t)(per_cu * ncu);
+  uint32_t grid = (uint32_t)(4 * ncu);
   if (grid > nchunks) grid = nchunks;
   if (grid == 0) grid = 1;
   hipLaunchKernelGGL(k_histogram, dim3(grid), dim3(kHistThreads), 0, s, d_in, n, chunk_log2, nchunks, d_chunk_hist,
@@ -952,6 +951,18 @@ struct DecLds {
   int status0;
 };
 
+__device__ __forceinline__ void dec_lds_load(DecLds& L, const DecTables* dt, int tid, int nthreads) {
+  const int lut_bits = dt->lut_bits;
+  const uint4* src = reinterpret_cast<const uint4*>(dt->lut);
+  uint4* dst = reinterpret_cast<uint4*>(L.lut);
+  for (int i = tid; i < ((1 << lut_bits) * 2 + 15) / 16; i += nthreads) dst[i] = src[i];
+  if (tid < 36) {
+    L.fcl[tid] = dt->fc_left[tid];
+    L.sp[tid] = dt->start_pos[tid];
+  }
+  for (int i = tid; i < GHF_NSYM; i += nthreads) L.symbol[i] = dt->symbol[i];
+}
+
 // codes longer than the direct table: the reference's linear extension (canonical_huff_encoder.cc:554-557).
 // returns sym | len << 16
 __device__ __forceinline__ uint32_t dec_long(const DecLds& L, uint32_t hi, int lut_bits, int max_len) {
@@ -975,177 +986,239 @@ struct DecIn {
   }
 };
 
-// decode this lane's segment (cnt symbols starting at bit `pos` of the span) and store the bytes.
-// returns 256-flagged garbage accumulator: bit 8 set <=> corrupt.
-template <bool STAGED>
+// Decode this lane's segment (cnt symbols starting at bit `pos` of the span) and store the bytes.
+// The window W holds 64 stream bits, `o` of them (from the top) already consumed; one symbol costs a 64-bit
+// shift, the table lookup and an add.  K symbols are decoded between two refill checks -- the caller picks
+// K = 32 / max_len (<= 4), which keeps o + max_len <= 64 at every lookup -- and LONG says whether codes longer
+// than the direct table exist at all.  Returns an accumulator whose bit 8 is set when something is wrong.
+template <bool STAGED, int K, bool LONG>
 __device__ __forceinline__ uint32_t decode_segment(const DecLds& L, const DecIn<STAGED>& I, int lut_bits, int max_len,
                                                    uint64_t pos, uint32_t cnt, bool valid, bool all_full, uint8_t* optr,
                                                    bool has_next, uint64_t expect_bits) {
   const int lsh = 32 - lut_bits;
   uint32_t widx = (uint32_t)(pos >> 5);
-  const uint32_t off = (uint32_t)(pos & 31u);
-  uint64_t window = (((uint64_t)I.fetch(widx) << 32) | I.fetch(widx + 1)) << off;
+  uint32_t o = (uint32_t)(pos & 31u);
+  const uint32_t o0 = o, widx0 = widx;
+  uint64_t W = ((uint64_t)I.fetch(widx) << 32) | I.fetch(widx + 1);
   uint32_t nextw = I.fetch(widx + 2);
   widx += 3;
-  int avail = 64 - (int)off;
-  uint32_t used = 0, bad_acc = 0;
+  uint32_t bad_acc = 0;
 
-#define GHF_DEC_ONE(SYM)                                 \
-  do {                                                   \
-    if (avail < 32) {                                    \
-      window |= (uint64_t)nextw << (32 - avail);         \
-      avail += 32;                                       \
-      nextw = I.fetch(widx++);                           \
-    }                                                    \
-    const uint32_t hi_ = (uint32_t)(window >> 32);       \
-    uint32_t ent_ = L.lut[hi_ >> lsh];                   \
-    uint32_t len_ = ent_ >> 9;                           \
-    SYM = ent_ & 0x1FFu;                                 \
-    if (__builtin_expect(len_ == 0, 0)) {                \
-      ent_ = dec_long(L, hi_, lut_bits, max_len);        \
-      len_ = ent_ >> 16;                                 \
-      SYM = ent_ & 0xFFFFu;                              \
-    }                                                    \
-    window <<= len_;                                     \
-    avail -= (int)len_;                                  \
-    used += len_;                                        \
+#define GHF_REFILL()                 \
+  if (o >= 32u) {                    \
+    W = (W << 32) | nextw;           \
+    o -= 32u;                        \
+    nextw = I.fetch(widx++);         \
+  }
+#define GHF_DEC(ENT)                                          \
+  do {                                                        \
+    const uint32_t v_ = (uint32_t)((W << o) >> 32);           \
+    ENT = L.lut[v_ >> lsh];                                   \
+    if (LONG && __builtin_expect((ENT >> 9) == 0, 0)) {       \
+      const uint32_t r_ = dec_long(L, v_, lut_bits, max_len); \
+      ENT = (r_ & 0x1FFu) | ((r_ >> 16) << 9);                \
+    }                                                         \
+    o += ENT >> 9;                                            \
   } while (0)
 
-  if (all_full) {
+  if (STAGED && all_full) {
     // full segments everywhere (all groups but the stream's last): 16 output bytes per store
+#pragma unroll 1
     for (int q = 0; q < 4; ++q) {
       uint32_t wq[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        uint32_t s0, s1, s2, s3;
-        GHF_DEC_ONE(s0);
-        GHF_DEC_ONE(s1);
-        GHF_DEC_ONE(s2);
-        GHF_DEC_ONE(s3);
-        bad_acc |= (s0 | s1 | s2 | s3);
-        wq[k] = (s0 & 0xFFu) | ((s1 & 0xFFu) << 8) | ((s2 & 0xFFu) << 16) | (s3 << 24);
+        uint32_t e[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          if ((4 * k + jj) % K == 0) GHF_REFILL();
+          GHF_DEC(e[jj]);
+        }
+        bad_acc |= e[0] | e[1] | e[2] | e[3];
+        // byte 0 of four entries -> one dword (v_perm_b32): {a.b0, b.b0} then {lo16, hi16}
+        const uint32_t lo = __builtin_amdgcn_perm(e[1], e[0], 0x0C0C0400u);
+        const uint32_t hi = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0400u);
+        wq[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
       }
       if (valid) *reinterpret_cast<uint4*>(optr + q * 16) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
     }
   } else if (valid) {
     for (uint32_t i = 0; i < cnt; ++i) {
-      uint32_t sy;
-      GHF_DEC_ONE(sy);
-      bad_acc |= sy;
-      optr[i] = (uint8_t)sy;
+      uint32_t e;
+      GHF_REFILL();
+      GHF_DEC(e);
+      bad_acc |= e;
+      optr[i] = (uint8_t)e;
     }
   }
   if (valid) {
     // the index says where the next segment starts: an end-to-end check of every segment
     if (has_next) {
-      if ((uint64_t)used != expect_bits) bad_acc |= 256u;
+      const uint64_t used = (uint64_t)(widx - widx0 - 3) * 32 + o - o0;
+      if (used != expect_bits) bad_acc |= 256u;
     } else {
-      uint32_t sy;
-      GHF_DEC_ONE(sy);
-      if (sy != 256u) bad_acc |= 256u;  // canonical_huff_encoder.cc:404: the end mark must follow
-      else bad_acc &= ~256u;
+      uint32_t e;
+      GHF_REFILL();
+      GHF_DEC(e);
+      if ((e & 0x1FFu) != 256u) bad_acc |= 256u;  // canonical_huff_encoder.cc:404: the end mark must follow
     }
   }
-#undef GHF_DEC_ONE
-  return bad_acc;
+#undef GHF_DEC
+#undef GHF_REFILL
+  return bad_acc & 256u;
 }
 
 // K7.  Persistent waves; each pass a wave takes 64 consecutive segments (4096 symbols):
 //   1. the compressed span of those segments (known from the side-car) is copied into LDS with
 //      coalesced 16-byte loads, byte-swapped to big-endian words;
-//   2. every lane decodes its 64 symbols from a left-justified 64-bit window: one LDS table lookup
-//      per symbol, the next 32-bit word is prefetched one refill ahead;
+//   2. every lane decodes its 64 symbols from a 64-bit window: one LDS table lookup per symbol;
 //   3. every 16 symbols the lane stores 16 output bytes straight to HBM (its 64 bytes are contiguous).
-__global__ __launch_bounds__(kDecThreads) void k_decode(DecParams P) {
+// The loop is software-pipelined over groups so that no HBM latency is exposed: while group i is decoded,
+// the span of group i+1 is in flight into registers and the side-car entries of group i+2 are in flight too.
+struct DecGroup {      // what a lane knows about its segment in one group (all per-lane unless noted)
+  uint64_t sbit, nbit; // start bit of my segment / of the next one
+  uint64_t byte0;      // uniform: first staged byte (16-aligned)
+  uint64_t span;       // uniform: staged bytes
+};
+
+__device__ __forceinline__ void dec_load_meta(const DecParams& P, uint64_t group, int lane, uint64_t& sbit, uint64_t& nbit) {
+  const uint64_t stream_end_bit = P.stream_bytes * 8;
+  const uint64_t seg = group * 64 + lane;
+  sbit = stream_end_bit;
+  nbit = stream_end_bit;
+  if (seg < P.n_segs) sbit = P.chunk_bit[(seg * kSegSymbols) >> P.chunk_log2] + P.seg_bit[seg];
+  if (seg + 1 < P.n_segs) nbit = P.chunk_bit[((seg + 1) * kSegSymbols) >> P.chunk_log2] + P.seg_bit[seg + 1];
+}
+
+__device__ __forceinline__ void dec_span(const DecParams& P, uint64_t group, int lane, int max_len, DecGroup& G) {
+  const uint64_t stream_end_bit = P.stream_bytes * 8;
+  const uint64_t seg0 = group * 64;
+  const bool valid = seg0 + lane < P.n_segs;
+  const uint64_t B0 = __shfl(G.sbit, 0, 64);
+  uint64_t B1 = __shfl(G.nbit, 63, 64);
+  if (seg0 + 64 >= P.n_segs) {
+    // last group: nothing tells where it ends; bound it by its last segment's worst case (+ end mark)
+    uint64_t m = valid ? G.sbit + 65ull * (uint64_t)max_len : 0ull;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint64_t o = __shfl_xor(m, d, 64);
+      m = o > m ? o : m;
+    }
+    B1 = m < stream_end_bit ? m : stream_end_bit;
+  }
+  G.byte0 = (B0 >> 3) & ~15ull;
+  uint64_t byte1 = ((B1 + 7) >> 3) + 12;  // window look-ahead
+  if (byte1 > P.stream_bytes) byte1 = P.stream_bytes;
+  if (G.byte0 > byte1) G.byte0 = byte1 & ~15ull;  // corrupt side-car: caught by the checks below
+  G.span = byte1 - G.byte0;
+}
+
+constexpr int kDecVec = kDecInBytes / 1024;  // 16-byte vectors per lane that cover a staged span
+
+__global__ __launch_bounds__(kDecThreads, 5) void k_decode(DecParams P) {
   __shared__ DecLds L;
   const int tid = threadIdx.x;
   if (tid == 0) L.status0 = *P.status;  // one read per workgroup: the exit must be uniform
   __syncthreads();
   if (L.status0 != 0) return;
   const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(P.dt->lut);
-    uint4* dst = reinterpret_cast<uint4*>(L.lut);
-    for (int i = tid; i < ((1 << lut_bits) * 2 + 15) / 16; i += kDecThreads) dst[i] = src[i];
-  }
-  if (tid < 36) {
-    L.fcl[tid] = P.dt->fc_left[tid];
-    L.sp[tid] = P.dt->start_pos[tid];
-  }
-  for (int i = tid; i < GHF_NSYM; i += kDecThreads) L.symbol[i] = P.dt->symbol[i];
+  dec_lds_load(L, P.dt, tid, kDecThreads);
   __syncthreads();
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar loop control
   const uint64_t ngroups = (P.n_segs + 63) >> 6;
   const uint64_t gstride = (uint64_t)gridDim.x * kDecWaves;
   const uint64_t stream_end_bit = P.stream_bytes * 8;
+  const uint64_t full_bytes = P.stream_bytes & ~15ull;  // whole 16-byte vectors of the stream
   const bool out_aligned = (((uintptr_t)P.out) & 15u) == 0;
   uint32_t* in = L.in[wave];
   uint32_t bad_acc = 0;
+  uint64_t group = (uint64_t)blockIdx.x * kDecWaves + wave;
+  if (group >= ngroups) return;
+  const uint64_t glast = ngroups - 1;
+  auto clampg = [&](uint64_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
 
-  for (uint64_t group = (uint64_t)blockIdx.x * kDecWaves + wave; group < ngroups; group += gstride) {
+  // issue the 16-byte loads of a group's span (vector k of this lane = bytes byte0 + k*1024 + lane*16 ..)
+  auto issue = [&](const DecGroup& G, uint4 (&R)[kDecVec]) {
+#pragma unroll
+    for (int k = 0; k < kDecVec; ++k) {
+      const uint64_t o = (uint64_t)k * 1024 + (uint64_t)lane * 16;
+      const bool ok = G.byte0 + o + 16 <= full_bytes;
+      R[k] = *reinterpret_cast<const uint4*>(P.stream + (ok ? G.byte0 + o : 0));
+    }
+  };
+
+  DecGroup cur, nxt;
+  uint4 R[kDecVec];
+  uint64_t sbit2, nbit2;  // side-car entries of the group after next
+  dec_load_meta(P, group, lane, cur.sbit, cur.nbit);
+  dec_span(P, group, lane, max_len, cur);
+  issue(cur, R);
+  dec_load_meta(P, clampg(group + gstride), lane, nxt.sbit, nxt.nbit);
+
+  for (; group < ngroups; group += gstride) {
+    // ---- 1. this group's span: registers -> LDS (big-endian words); everything behind it reads as zero
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < kDecVec; ++k) {
+      const uint64_t o = (uint64_t)k * 1024 + (uint64_t)lane * 16;
+      const bool ok = (o < cur.span) && (cur.byte0 + o + 16 <= full_bytes);
+      uint4 v = R[k];
+      v = ok ? make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)) : make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(in + (o >> 2)) = v;
+    }
+    if (lane < 4) in[kDecInWords + lane] = 0;
+    if (cur.byte0 + cur.span > full_bytes && full_bytes >= cur.byte0 && lane == 0) {
+      // the stream's last, incomplete 16 bytes: byte loads, never past the end of the buffer
+      uint32_t q[4] = {0, 0, 0, 0};
+      for (uint64_t j = 0; full_bytes + j < P.stream_bytes; ++j) q[j >> 2] |= (uint32_t)P.stream[full_bytes + j] << (24 - 8 * (j & 3));
+      const uint64_t w = (full_bytes - cur.byte0) >> 2;
+      if (w + 3 < (uint64_t)kDecInWords + 4) {
+        in[w] = q[0]; in[w + 1] = q[1]; in[w + 2] = q[2]; in[w + 3] = q[3];
+      }
+    }
+    wave_sync();
+    // ---- prefetch: span of the next group (its side-car entries arrived during the last decode), side-car of the one after
+    const uint64_t gn = clampg(group + gstride);
+    dec_span(P, gn, lane, max_len, nxt);
+    issue(nxt, R);
+    dec_load_meta(P, clampg(group + 2 * gstride), lane, sbit2, nbit2);
+    // ---- 2./3. decode
     const uint64_t seg0 = group * 64;
     const uint64_t seg = seg0 + lane;
     const bool valid = seg < P.n_segs;
-    // start bit of this lane's segment and of the one after it (bits counted from d_stream[0])
-    uint64_t sbit = stream_end_bit, nbit = stream_end_bit;
-    if (valid) sbit = P.chunk_bit[(seg * kSegSymbols) >> P.chunk_log2] + P.seg_bit[seg];
-    if (seg + 1 < P.n_segs) nbit = P.chunk_bit[((seg + 1) * kSegSymbols) >> P.chunk_log2] + P.seg_bit[seg + 1];
-    const uint64_t B0 = __shfl(sbit, 0, 64);
-    uint64_t B1 = __shfl(nbit, 63, 64);
-    if (seg0 + 64 >= P.n_segs) {
-      // last group: nothing tells where it ends; bound it by its last segment's worst case (+ end mark)
-      uint64_t m = valid ? sbit + 65ull * (uint64_t)max_len : 0ull;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        const uint64_t o = __shfl_xor(m, d, 64);
-        m = o > m ? o : m;
-      }
-      B1 = m < stream_end_bit ? m : stream_end_bit;
-    }
-    const bool bad = valid && (sbit >= stream_end_bit || nbit > stream_end_bit || nbit < sbit);
+    const bool bad = valid && (cur.sbit >= stream_end_bit || cur.nbit > stream_end_bit || cur.nbit < cur.sbit ||
+                               cur.sbit < cur.byte0 * 8);
     if (__ballot(bad)) {
       if (bad) latch_status(P.status, GHF_E_CORRUPT);
-      continue;
-    }
-    // ---- 1. stage the span
-    const uint64_t byte0 = ((B0 >> 3) & ~15ull);
-    uint64_t byte1 = ((B1 + 7) >> 3) + 12;  // window look-ahead
-    if (byte1 > P.stream_bytes) byte1 = P.stream_bytes;
-    const uint64_t span = byte1 - byte0;
-    const uint8_t* src = P.stream + byte0;
-    const bool staged = span <= (uint64_t)kDecInBytes;
-    wave_sync();
-    if (staged) {
-      for (uint64_t o = (uint64_t)lane * 16; o < span; o += 1024) {
-        uint4 v;
-        if (o + 16 <= span) {
-          v = *reinterpret_cast<const uint4*>(src + o);
-        } else {
-          uint32_t q[4] = {0, 0, 0, 0};
-          for (uint32_t j = 0; o + j < span; ++j) q[j >> 2] |= (uint32_t)src[o + j] << (8 * (j & 3));
-          v = make_uint4(q[0], q[1], q[2], q[3]);
-        }
-        *reinterpret_cast<uint4*>(in + (o >> 2)) = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
-      }
-      const uint32_t wend = (uint32_t)((span + 15) >> 4) << 2;
-      if (lane < 4 && wend + lane < (uint32_t)kDecInWords + 4) in[wend + lane] = 0;
-    }
-    wave_sync();
-    // ---- 2./3. decode
-    const uint64_t sym0 = seg * kSegSymbols;
-    uint32_t cnt = 0;
-    if (valid) cnt = (P.n_symbols - sym0 >= (uint64_t)kSegSymbols) ? (uint32_t)kSegSymbols : (uint32_t)(P.n_symbols - sym0);
-    const uint64_t pos = sbit - byte0 * 8;
-    const bool all_full = (__ballot(valid && cnt != (uint32_t)kSegSymbols) == 0) && out_aligned;
-    const bool has_next = seg + 1 < P.n_segs;
-    if (staged) {
-      DecIn<true> I{in, src, span};
-      bad_acc |= decode_segment<true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, P.out + sym0, has_next, nbit - sbit);
     } else {
-      DecIn<false> I{in, src, span};
-      bad_acc |= decode_segment<false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, P.out + sym0, has_next, nbit - sbit);
+      const bool staged = cur.span <= (uint64_t)kDecInBytes;
+      const uint64_t sym0 = seg * kSegSymbols;
+      uint32_t cnt = 0;
+      if (valid) cnt = (P.n_symbols - sym0 >= (uint64_t)kSegSymbols) ? (uint32_t)kSegSymbols : (uint32_t)(P.n_symbols - sym0);
+      const uint64_t pos = cur.sbit - cur.byte0 * 8;
+      const bool all_full = (__ballot(valid && cnt != (uint32_t)kSegSymbols) == 0) && out_aligned;
+      const bool has_next = seg + 1 < P.n_segs;
+      uint8_t* optr = P.out + sym0;
+      const uint64_t expect = cur.nbit - cur.sbit;
+      const uint8_t* src = P.stream + cur.byte0;
+      if (staged) {
+        DecIn<true> I{in, src, cur.span};
+        // K = 32 / max_len symbols per refill check; LONG = codes beyond the direct table exist
+        if (max_len <= 8) bad_acc |= decode_segment<true, 4, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
+        else if (max_len <= 10) bad_acc |= decode_segment<true, 3, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
+        else if (max_len <= kDecLutBitsMax) bad_acc |= decode_segment<true, 2, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
+        else if (max_len <= 16) bad_acc |= decode_segment<true, 2, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
+        else bad_acc |= decode_segment<true, 1, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
+      } else {
+        DecIn<false> I{in, src, cur.span};
+        bad_acc |= decode_segment<false, 1, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
+      }
     }
+    // ---- rotate (all of these values have long arrived)
+    cur = nxt;
+    nxt.sbit = sbit2;
+    nxt.nbit = nbit2;
   }
   if (bad_acc & 256u) latch_status(P.status, GHF_E_CORRUPT);  // a data symbol can never be 256
 }
@@ -1203,18 +1276,6 @@ __device__ __forceinline__ uint32_t dec_any(const DecLds& L, uint32_t hi, int lu
   const uint32_t r = dec_long(L, hi, lut_bits, max_len);
   len = r >> 16;
   return r & 0xFFFFu;
-}
-
-__device__ __forceinline__ void dec_lds_load(DecLds& L, const DecTables* dt, int tid, int nthreads) {
-  const int lut_bits = dt->lut_bits;
-  const uint4* src = reinterpret_cast<const uint4*>(dt->lut);
-  uint4* dst = reinterpret_cast<uint4*>(L.lut);
-  for (int i = tid; i < ((1 << lut_bits) * 2 + 15) / 16; i += nthreads) dst[i] = src[i];
-  if (tid < 36) {
-    L.fcl[tid] = dt->fc_left[tid];
-    L.sp[tid] = dt->start_pos[tid];
-  }
-  for (int i = tid; i < GHF_NSYM; i += nthreads) L.symbol[i] = dt->symbol[i];
 }
 
 // stage the bits of 64 consecutive subsequences (+ look-ahead) of the body into this wave's LDS words;
