@@ -39,6 +39,8 @@ struct ghf_ctx {
   ghf_index fidx = {};  // side-car rebuilt for the last foreign stream
   uint64_t* d_seg_abs = nullptr;
   size_t fidx_cap_segs = 0, fidx_cap_chunks = 0;
+  const uint8_t* fidx_stream = nullptr;  // which stream c->fidx currently describes
+  size_t fidx_bytes = 0;
   std::string err;
 };
 
@@ -548,6 +550,20 @@ static int rebuild_index(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
   ix.n_segs = n_segs;
   if (n) launch_sync_index(p, c->d_seg_abs, n_segs, cl, ix.d_chunk_bit, ix.d_seg_bit, c->stream);
   GHF_HIP(c, hipGetLastError());
+  c->fidx_stream = d_stream;
+  c->fidx_bytes = stream_bytes;
+  return GHF_OK;
+}
+
+int ghf_decoded_size(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code, uint64_t* n_out) {
+  if (!c || !d_stream || !d_code || !n_out) return GHF_E_INVAL;
+  if (!aligned16(d_stream)) return fail(c, GHF_E_INVAL, "d_stream must be 16-byte aligned");
+  GHF_HIP(c, hipSetDevice(c->device));
+  launch_build_decode_tables(d_code, c->d_dt, c->d_status, c->stream);
+  c->fidx_stream = nullptr;
+  const int rc = rebuild_index(c, d_stream, stream_bytes, d_code, (size_t)-1);
+  if (rc) return rc;
+  *n_out = c->fidx.n_symbols;
   return GHF_OK;
 }
 
@@ -558,8 +574,11 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
   GHF_HIP(c, hipSetDevice(c->device));
   launch_build_decode_tables(d_code, c->d_dt, c->d_status, c->stream);
   if (!index) {
-    const int rc = rebuild_index(c, d_stream, stream_bytes, d_code, cap);
-    if (rc) return rc;
+    if (c->fidx_stream != d_stream || c->fidx_bytes != stream_bytes) {  // else: ghf_decoded_size already did it
+      const int rc = rebuild_index(c, d_stream, stream_bytes, d_code, cap);
+      if (rc) return rc;
+    }
+    c->fidx_stream = nullptr;  // single use: the buffer may be rewritten afterwards
     index = &c->fidx;
   }
   if (!index->d_chunk_bit || !index->d_seg_bit || index->seg_symbols != (uint32_t)kSegSymbols ||

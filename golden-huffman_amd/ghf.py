@@ -64,7 +64,7 @@ EXPORTS = [
     "ghf_last_error", "ghf_status_string", "ghf_version", "ghf_device_alloc", "ghf_device_free", "ghf_host_alloc",
     "ghf_host_free", "ghf_copy_h2d", "ghf_copy_d2h", "ghf_memset_d", "ghf_histogram", "ghf_build_code",
     "ghf_write_header", "ghf_header_bytes", "ghf_encode_plan", "ghf_encode_emit", "ghf_compress", "ghf_compress_bound",
-    "ghf_chunk_symbols", "ghf_index_alloc", "ghf_index_free", "ghf_parse_header", "ghf_decode",
+    "ghf_chunk_symbols", "ghf_index_alloc", "ghf_index_free", "ghf_parse_header", "ghf_decode", "ghf_decoded_size",
 ]
 
 _lib = None
@@ -119,6 +119,7 @@ def lib():
     L.ghf_index_free.argtypes = [vp, C.POINTER(Index)]
     L.ghf_parse_header.argtypes = [vp, sz, C.POINTER(Code), C.POINTER(sz)]
     L.ghf_decode.argtypes = [vp, vp, sz, vp, C.POINTER(Index), vp, sz, vp]
+    L.ghf_decoded_size.argtypes = [vp, vp, sz, vp, C.POINTER(u64)]
     _lib = L
     return L
 
@@ -259,6 +260,11 @@ class Context:
                                 d_code.data_ptr(), None if index is None else C.byref(index)),
             "ghf_compress")
         return d_out, nbytes, d_code
+
+    def decoded_size(self, d_stream, stream_bytes, d_code):
+        n = C.c_uint64(0)
+        self._chk(self.L.ghf_decoded_size(self.h, d_stream.data_ptr(), stream_bytes, d_code.data_ptr(), C.byref(n)), "ghf_decoded_size")
+        return n.value
 
     def decode(self, d_stream, stream_bytes, d_code, index=None, d_out=None, cap=None):
         """index=None: a stream without side-car (e.g. written by the reference); the library rebuilds it on the GPU."""

@@ -151,6 +151,12 @@ int ghf_parse_header(const uint8_t* h_stream, size_t n, ghf_code* code, size_t* 
 int ghf_decode(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code,
                const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes);
 
+/* Size of what a side-car-less stream decodes to (the .crs2 format does not store it: the reference's
+ * decoders simply run until the end mark, include/canonical_huff_encoder.cc:404-411).  Rebuilds the
+ * side-car on the GPU, synchronises, and keeps it for a following ghf_decode(index = NULL) of the same
+ * (d_stream, stream_bytes), which then does not repeat the work. */
+int ghf_decoded_size(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code, uint64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

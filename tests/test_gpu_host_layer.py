@@ -1,0 +1,75 @@
+"""GPU (-m gpu): the C++ host layer (golden-huffman_amd/host/glzip_hip.h), i.e. the reference's
+Compressor<Encoder>/Decompressor<Decoder> API on the HIP policies, driven exactly like the reference's
+unit_tests/test.cc drives its own classes (BASELINE config 1: 1 MiB enwik-style ASCII, file to file)."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cases import CASES
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+TOOL = os.path.join(ROOT, "golden-huffman_amd", "host", "bin", "ghf_tool")
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def tool():
+    if not os.path.exists(TOOL):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "golden-huffman_amd", "host")], check=True)
+    return TOOL
+
+
+def test_config1_suite_like_unit_tests_test_cc(tool, tmp_path, golden):
+    data = CASES["text_1m"]()
+    f = tmp_path / "text_1m.bin"
+    data.tofile(f)
+    r = subprocess.run([tool, str(f)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "7 tests ran, 0 failed" in r.stdout
+    crs = np.fromfile(str(f) + ".crs2", dtype=np.uint8)  # default name: <in>.crs2 (canonical_huff_encoder.cc:19-22)
+    assert sha(crs) == golden["text_1m"]["crs2_sha256"]
+    de = np.fromfile(str(f) + ".crs2.de", dtype=np.uint8)  # default name: <in>.de (encoder.h:229-230)
+    assert np.array_equal(de, data)
+
+
+@pytest.mark.parametrize("name", ["aaaabbc", "single_x", "all256_once", "zipf_64k", "fib32_maxlen32", "uniform_65537"])
+def test_mode_switch_compress_then_three_decoders(tool, tmp_path, golden, name):
+    data = CASES[name]()
+    f = tmp_path / (name + ".bin")
+    data.tofile(f)
+    assert subprocess.run([tool, str(f), "3"], timeout=120).returncode == 0
+    crs = np.fromfile(str(f) + ".crs2", dtype=np.uint8)
+    assert crs.size == golden[name]["crs2_bytes"] and sha(crs) == golden[name]["crs2_sha256"]
+    for mode in ("4", "5", "6"):
+        out = str(f) + ".crs2.de"
+        if os.path.exists(out):
+            os.remove(out)
+        assert subprocess.run([tool, str(f) + ".crs2", mode], timeout=120).returncode == 0
+        assert np.array_equal(np.fromfile(out, dtype=np.uint8), data)
+
+
+def test_decodes_a_file_written_by_the_reference(tool, tmp_path):
+    """the .crs2 here comes from the oracle, byte-identical to the compiled reference's output"""
+    data = CASES["text_131073"]()
+    f = tmp_path / "ref.crs2"
+    orc.compress(data).tofile(f)
+    assert subprocess.run([tool, str(f), "4"], timeout=120).returncode == 0
+    assert np.array_equal(np.fromfile(str(f) + ".de", dtype=np.uint8), data)
+
+
+def test_errors_are_reported_not_undefined(tool, tmp_path):
+    empty = tmp_path / "empty.bin"
+    empty.write_bytes(b"")
+    assert subprocess.run([tool, str(empty), "3"], capture_output=True, timeout=60).returncode == 1
+    junk = tmp_path / "junk.crs2"
+    junk.write_bytes(bytes(range(256)) * 8)
+    assert subprocess.run([tool, str(junk), "4"], capture_output=True, timeout=60).returncode == 1
+    assert subprocess.run([tool, str(tmp_path / "missing.bin"), "3"], capture_output=True, timeout=60).returncode == 1
