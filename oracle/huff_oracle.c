@@ -228,6 +228,30 @@ size_t orc_encode_body(const uint8_t* in, size_t n, const orc_code* c, uint8_t* 
   return w.overflow ? (size_t)-1 : w.cur;
 }
 
+/* test helper for the sharded (multi-GPU) path, SURVEY 8(e): pack the codes of in[0..n) MSB-first starting at bit
+ * `phase` (0..7) of out[0] -- the bits in front stay zero --, optionally followed by the end mark and the
+ * 1-padding (canonical_huff_encoder.cc:255-257).  Returns the bits written behind the phase, or (uint64_t)-1. */
+uint64_t orc_pack_at(const uint8_t* in, size_t n, const orc_code* c, unsigned phase, int last, uint8_t* out, size_t cap) {
+  orc_bitw w = {out, cap, 0, 0, 0, 0};
+  uint64_t bits = 0;
+  for (unsigned i = 0; i < phase; i++) w_bit(&w, 0);
+  for (size_t i = 0; i < n; i++) {
+    w_bits(&w, c->codeword[in[i]], (int)c->length[in[i]]);
+    bits += c->length[in[i]];
+  }
+  if (last) {
+    w_bits(&w, c->codeword[ORC_NSYM - 1], (int)c->length[ORC_NSYM - 1]);
+    bits += c->length[ORC_NSYM - 1];
+    while ((8 - w.bit_cur) % 8) {
+      w_bit(&w, 1);
+      bits++;
+    }
+  } else {
+    while ((8 - w.bit_cur) % 8) w_bit(&w, 0); /* the next shard ORs its bits in here */
+  }
+  return w.overflow ? (uint64_t)-1 : bits;
+}
+
 uint64_t orc_body_bits(const int64_t hist[ORC_NSYM], const orc_code* c) {
   uint64_t bits = 0;
   for (int i = 0; i < 256; i++) bits += (uint64_t)hist[i] * c->length[i];

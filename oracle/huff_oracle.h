@@ -65,6 +65,9 @@ size_t orc_parse_header(const uint8_t* in, size_t n, orc_code* c);
 int orc_decode_body(const uint8_t* body, size_t body_n, const orc_code* c, uint8_t* out, size_t cap, size_t* out_n);
 int orc_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_n);
 
+/* sharded-path helper (tests only): pack at a bit phase, optionally with end mark + padding */
+uint64_t orc_pack_at(const uint8_t* in, size_t n, const orc_code* c, unsigned phase, int last, uint8_t* out, size_t cap);
+
 /* total body bits incl. the EOF code, before padding */
 uint64_t orc_body_bits(const int64_t hist[ORC_NSYM], const orc_code* c);
 

@@ -82,6 +82,8 @@ def lib():
         L.orc_decode_body.restype = C.c_int
         L.orc_decompress.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.orc_decompress.restype = C.c_int
+        L.orc_pack_at.argtypes = [u8p, C.c_size_t, C.POINTER(OrcCode), C.c_uint, C.c_int, u8p, C.c_size_t]
+        L.orc_pack_at.restype = C.c_uint64
         L.orc_body_bits.argtypes = [C.POINTER(C.c_int64), C.POINTER(OrcCode)]
         L.orc_body_bits.restype = C.c_uint64
         _lib = L

@@ -1,0 +1,100 @@
+"""GPU (-m gpu): the multi-GPU path on the one GPU this box has -- two ranks (processes) share cuda:0, the real
+kernels run with GHF_EMIT_REBASE / bit-phase start offsets, the two collectives go over gloo (staged through the
+host, since NCCL/RCCL refuses two ranks on one device).  The 8-GPU RCCL run is the driver's; this pins the
+kernel side of it: shard streams OR-merge to the single-stream .crs2, and every rank decodes its own shard."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class HostStagedDist:
+    """torch.distributed look-alike whose tensor collectives bounce through CPU tensors (gloo)"""
+
+    def __init__(self, dist):
+        self.d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def get_rank(self, group=None):
+        return self.d.get_rank()
+
+    def get_world_size(self, group=None):
+        return self.d.get_world_size()
+
+    def all_reduce(self, t, op=None, group=None):
+        c = t.cpu()
+        self.d.all_reduce(c, op=op)
+        t.copy_(c)
+
+    def all_gather_into_tensor(self, out, t, group=None):
+        parts = [torch.zeros_like(t.cpu()) for _ in range(self.d.get_world_size())]
+        self.d.all_gather(parts, t.cpu())
+        out.copy_(torch.cat(parts))
+
+    def all_gather_object(self, lst, obj, group=None):
+        self.d.all_gather_object(lst, obj)
+
+    def barrier(self):
+        self.d.barrier()
+
+
+def _worker(rank, world, port, kind, n_total, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datagen as dg
+    import pkgload
+
+    pkg = pkgload.load()
+    from golden_huffman_amd import sharded
+
+    ctx = pkg.ghf.Context(0)
+    hd = HostStagedDist(dist)
+    lo, hi = rank * n_total // world, (rank + 1) * n_total // world
+    data = dg.make(kind, hi - lo, seed=9, offset=lo)
+    shard = torch.from_numpy(data).cuda()
+    index = ctx.index_alloc(shard.numel())
+    enc = sharded.encode_sharded(ctx, hd, shard, index=index)
+    ctx.sync()
+    back, _ = sharded.decode_sharded(ctx, enc, index)
+    ctx.sync()
+    ok = bool((back[: shard.numel()] == shard).all().item())
+    stream = sharded.gather_stream(ctx, hd, enc)
+    q.put((rank, ok, stream.tobytes() if rank == 0 else None))
+    dist.barrier()
+    ctx.index_free(index)
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,n_total", [("zipf", 3 * (1 << 20) + 17), ("uniform", 1 << 21), ("sym16", 777777)])
+def test_two_ranks_on_one_gpu(kind, n_total):
+    import datagen as dg
+    from oracle import oracle as orc
+
+    world = 2
+    port = 29700 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(g[1] for g in got), "a rank failed to decode its own shard"
+    stream = next(g[2] for g in got if g[2] is not None)
+    ref = orc.compress(dg.make(kind, n_total, seed=9))
+    got_stream = np.frombuffer(stream, dtype=np.uint8)
+    assert got_stream.size == ref.size and np.array_equal(got_stream, ref)
