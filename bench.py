@@ -116,6 +116,7 @@ def main():
     dec = ctx.empty_u8(n)
     d_code = ctx.new_code()
     index = ctx.index_alloc(n)
+    index.flags = 0 if rank == world - 1 else ghf.INDEX_NO_END_MARK  # only the last shard ends with the end mark
     torch.cuda.synchronize()
 
     names = ["histogram", "allreduce", "build_code", "header", "plan", "allgather", "emit", "decode"]

@@ -596,6 +596,7 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
   uint32_t cl = 0;
   while ((1u << cl) < index->chunk_symbols) ++cl;
   p.chunk_log2 = cl;
+  p.no_end_mark = (index->flags & GHF_INDEX_NO_END_MARK) ? 1u : 0u;
   p.out = d_out;
   p.status = c->d_status;
   launch_decode(p, c->stream);

@@ -74,6 +74,7 @@ struct DecParams {
   uint64_t n_symbols;
   uint64_t n_segs;
   uint32_t chunk_log2;
+  uint32_t no_end_mark;  // the last symbol is not followed by the end mark (a shard that is not the stream's last)
   uint8_t* out;
   int* status;
 };

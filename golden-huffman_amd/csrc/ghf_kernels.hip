@@ -1068,7 +1068,7 @@ struct DecIn {
 template <bool STAGED, int K, bool LONG>
 __device__ __forceinline__ uint32_t decode_segment(const DecLds& L, const DecIn<STAGED>& I, int lut_bits, int max_len,
                                                    uint64_t pos, uint32_t cnt, bool valid, bool all_full, uint8_t* optr,
-                                                   bool has_next, uint64_t expect_bits) {
+                                                   int has_next, uint64_t expect_bits) {
   const int lsh = 32 - lut_bits;
   uint32_t widx = (uint32_t)(pos >> 5);
   uint32_t o = (uint32_t)(pos & 31u);
@@ -1127,10 +1127,10 @@ __device__ __forceinline__ uint32_t decode_segment(const DecLds& L, const DecIn<
   }
   if (valid) {
     // the index says where the next segment starts: an end-to-end check of every segment
-    if (has_next) {
+    if (has_next == 1) {
       const uint64_t used = (uint64_t)(widx - widx0 - 3) * 32 + o - o0;
       if (used != expect_bits) bad_acc |= 256u;
-    } else {
+    } else if (has_next == 0) {
       uint32_t e;
       GHF_REFILL();
       GHF_DEC(e);
@@ -1272,7 +1272,8 @@ __global__ __launch_bounds__(kDecThreads, 5) void k_decode(DecParams P) {
       if (valid) cnt = (P.n_symbols - sym0 >= (uint64_t)kSegSymbols) ? (uint32_t)kSegSymbols : (uint32_t)(P.n_symbols - sym0);
       const uint64_t pos = cur.sbit - cur.byte0 * 8;
       const bool all_full = (__ballot(valid && cnt != (uint32_t)kSegSymbols) == 0) && out_aligned;
-      const bool has_next = seg + 1 < P.n_segs;
+      // 1: the side-car says where the next segment starts; 0: the end mark must follow; 2: nothing to check
+      const int has_next = seg + 1 < P.n_segs ? 1 : (P.no_end_mark ? 2 : 0);
       uint8_t* optr = P.out + sym0;
       const uint64_t expect = cur.nbit - cur.sbit;
       const uint8_t* src = P.stream + cur.byte0;

@@ -7,6 +7,7 @@ import os
 NSYM = 257
 EMIT_LAST = 1
 EMIT_REBASE = 2
+INDEX_NO_END_MARK = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libghf.so")
@@ -54,6 +55,8 @@ class Index(C.Structure):
         ("seg_symbols", C.c_uint32),
         ("n_chunks", C.c_uint64),
         ("n_segs", C.c_uint64),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
         ("d_chunk_bit", C.c_void_p),
         ("d_seg_bit", C.c_void_p),
     ]

@@ -53,6 +53,8 @@ def encode_sharded(be, dist, d_in, out=None, index=None, group=None):
         flags |= be.EMIT_REBASE
     if out is None:
         out = be.empty_u8(be.compress_bound(n))
+    if index is not None:
+        index.flags = 0 if rank == world - 1 else 1  # GHF_INDEX_NO_END_MARK: this shard is not followed by the end mark
     if rank == 0:
         be.write_header(d_code, out)  # a5
     end = be.encode_emit(d_in, d_code, out, start_bit=start_bit, flags=flags, index=index)  # K5

@@ -57,10 +57,14 @@ typedef struct ghf_index {
   uint32_t seg_symbols;   /* symbols per segment (64) */
   uint64_t n_chunks;
   uint64_t n_segs;
+  uint32_t flags;    /* GHF_INDEX_NO_END_MARK: the buffer is a shard that was emitted without GHF_EMIT_LAST */
+  uint32_t reserved;
   uint64_t* d_chunk_bit; /* [n_chunks] bit offset of each chunk's first code, counted from byte 0 of the d_out the
                             emit call wrote into (= absolute stream bit, header included, unless GHF_EMIT_REBASE) */
   uint32_t* d_seg_bit;   /* [n_segs]   bit offset of each segment relative to its chunk's first code */
 } ghf_index;
+
+#define GHF_INDEX_NO_END_MARK 1u
 
 typedef struct ghf_ctx ghf_ctx;
 

@@ -39,7 +39,7 @@ def test_header_symbols_all_exported(ghf):
 
 def test_struct_layout_matches_header(ghf):
     assert C.sizeof(ghf.Code) == 4 * (3 * 257 + 2 * 64 + 2)
-    assert C.sizeof(ghf.Index) == 48
+    assert C.sizeof(ghf.Index) == 56
 
 
 def test_no_cpu_fallback_without_gpu(ghf):
