@@ -38,20 +38,26 @@ struct Error : public std::runtime_error {
 
 namespace detail {
 
-// one ghf_ctx per policy object ("one context per host thread/GPU")
+// one ghf_ctx per policy object ("one context per host thread/GPU"), created on first use so that a
+// default-constructed Compressor (file-scope objects in unit_tests/test.cc:45-46) touches no GPU
 class Session {
  public:
-  Session() : ctx_(NULL) {
-    int rc = ghf_ctx_create(device_from_env(), &ctx_);
-    if (rc) throw Error(rc, std::string("ghf_ctx_create: ") + ghf_status_string(rc) + " " + ghf_last_error(NULL));
+  Session() : ctx_(NULL) {}
+  ~Session() {
+    if (ctx_) ghf_ctx_destroy(ctx_);
   }
-  ~Session() { ghf_ctx_destroy(ctx_); }
-  ghf_ctx* ctx() const { return ctx_; }
+  ghf_ctx* ctx() const {
+    if (!ctx_) {
+      int rc = ghf_ctx_create(device_from_env(), &ctx_);
+      if (rc) throw Error(rc, std::string("ghf_ctx_create: ") + ghf_status_string(rc) + " " + ghf_last_error(NULL));
+    }
+    return ctx_;
+  }
   void check(int rc, const char* where) const {
     if (rc) throw Error(rc, std::string(where) + ": " + ghf_status_string(rc) + " " + ghf_last_error(ctx_));
   }
   void sync(const char* where) const {
-    int rc = ghf_sync(ctx_);
+    int rc = ghf_sync(ctx());
     if (rc) {
       ghf_clear_status(ctx_);
       throw Error(rc, std::string(where) + ": " + ghf_status_string(rc));
@@ -65,7 +71,7 @@ class Session {
  private:
   Session(const Session&);
   Session& operator=(const Session&);
-  ghf_ctx* ctx_;
+  mutable ghf_ctx* ctx_;
 };
 
 struct DeviceBuf {

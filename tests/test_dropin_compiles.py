@@ -1,0 +1,57 @@
+"""CPU, build container only: the HIP policy classes instantiate the REFERENCE's own, unmodified
+Compressor<>/Decompressor<> templates (include/compressor.h:44-95) -- the drop-in claim of INTEGRATION.md,
+checked by the compiler.  Nothing from the reference is copied: its header is only named on the include path."""
+import os
+import subprocess
+import textwrap
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+REF = "/root/reference"
+
+DRIVER = textwrap.dedent(
+    """
+    #include <string>
+    #include "compressor.h"      // the reference's framework templates, as they are
+    #include "glzip_hip.h"       // our policies
+    using glzip_hip::HipCanonicalHuffEncoder;
+    using glzip_hip::HipCanonicalHuffDecoder;
+    using glzip_hip::HipFastCanonicalHuffDecoder;
+    using glzip_hip::HipTableCanonicalHuffDecoder;
+    glzip::Compressor<HipCanonicalHuffEncoder<> > compressor2;   // by-value member + default ctor, like test.cc:46
+    int main(int argc, char** argv) {
+      if (argc < 2) return 0;                                     // link check only; running needs a GPU
+      std::string in(argv[1]), out, out2;
+      compressor2.set_file(in, out);
+      compressor2.compress();
+      compressor2.clear();
+      { glzip::Decompressor<HipCanonicalHuffDecoder<> > d(out, out2); d.decompress(); }
+      out2.clear();
+      { glzip::Decompressor<HipFastCanonicalHuffDecoder<> > d(out, out2); d.decompress(); }
+      out2.clear();
+      { glzip::Decompressor<HipTableCanonicalHuffDecoder<> > d(out, out2); d.decompress(); }
+      glzip::Compressor<HipCanonicalHuffEncoder<> > c2(in, out);  // the two-argument ctor, compressor.h:47-48
+      return 0;
+    }
+    """
+)
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not os.path.isdir(REF + "/include"), reason="the reference tree only exists in the build container")
+def test_reference_framework_templates_accept_the_hip_policies(tmp_path):
+    import pkgload
+
+    pkg = pkgload.load()
+    if not os.path.exists(pkg.ghf.LIB_PATH):
+        pkg.build()
+    src = tmp_path / "dropin.cc"
+    src.write_text(DRIVER)
+    exe = tmp_path / "dropin"
+    cmd = ["g++", "-std=gnu++17", "-w", "-I" + REF + "/include", "-I" + REF + "/utils/include", "-I" + ROOT + "/include",
+           "-I" + ROOT + "/golden-huffman_amd/host", str(src), "-o", str(exe), "-L" + os.path.dirname(pkg.ghf.LIB_PATH), "-lghf",
+           "-Wl,-rpath," + os.path.dirname(pkg.ghf.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert subprocess.run([str(exe)]).returncode == 0  # no arguments: no GPU work
