@@ -261,9 +261,24 @@ __device__ __forceinline__ u64t wave_heap_pop(HeapLds& h, int& n, int lane) {
   const U64x2 c1 = *reinterpret_cast<const U64x2*>(&h.slot[2 * (lane + 64) + 2]);
   const unsigned long long m0 = __ballot(heap_gt(c0.y, c0.x));
   const unsigned long long m1 = __ballot(heap_gt(c1.y, c1.x));
-  // 2. walk (scalar)
+  // 2. walk (scalar).  With D = depth of the last position, every node above depth D-1 has two children, so the
+  //    first D-1 steps need no bounds test, and all of them but a possible 7th stay below node 63 (map m0 only).
+  const int D = 31 - __clz(len);
+  const int steps = D - 1;
   int hole = 0, k = 0;
-  while (hole < lim) {
+#pragma unroll
+  for (int d = 0; d < 6; ++d) {
+    if (d < steps) {
+      hole = 2 * hole + 2 - (int)((m0 >> hole) & 1ull);
+      k = d + 1;
+    }
+  }
+  if (steps > 6) {  // len >= 256: one step from depth 6 (nodes 63..126)
+    const unsigned long long bit = (hole < 64 ? (m0 >> hole) : (m1 >> (hole - 64))) & 1ull;
+    hole = 2 * hole + 2 - (int)bit;
+    ++k;
+  }
+  if (hole < lim) {  // depth D-1 -> D where that node has both children
     const unsigned long long bit = (hole < 64 ? (m0 >> hole) : (m1 >> (hole - 64))) & 1ull;
     hole = 2 * hole + 2 - (int)bit;
     ++k;
@@ -280,8 +295,7 @@ __device__ __forceinline__ u64t wave_heap_pop(HeapLds& h, int& n, int lane) {
   const unsigned long long sm = __ballot(stop);
   const int m = sm ? 63 - __clzll((long long)sm) : 0;
   const u64t up = lane_above(e);
-  if (lane < m) h.slot[pj + 1] = up;
-  else if (lane == m) h.slot[pj + 1] = value;
+  if (lane <= m) h.slot[pj + 1] = (lane < m) ? up : value;
   return top;
 }
 
@@ -295,8 +309,7 @@ __device__ __forceinline__ void wave_heap_push(HeapLds& h, int n, u64t e, int la
   const unsigned long long sm = __ballot(stop);
   const int t = sm ? (__ffsll((long long)sm) - 1) - 1 : depth;  // entries of lanes 1..t move down one level
   const u64t up = lane_above(pe);
-  if (lane < t) h.slot[aj + 1] = up;
-  else if (lane == t) h.slot[aj + 1] = e;
+  if (lane <= t) h.slot[aj + 1] = (lane < t) ? up : e;
 }
 
 struct CodeLds {
@@ -609,7 +622,7 @@ struct E64 {  // codes up to 32 bits
 struct PairMode {
   typedef E32 E;
   static constexpr int N = 8;
-  static constexpr int kMinWaves = 4;
+  static constexpr int kMinWaves = 6;  // <= 80 VGPRs: three 8-wave workgroups per CU (LDS allows exactly three)
   static __device__ __forceinline__ bool applies(int max_len) { return max_len <= 16; }
 };
 struct MidMode {
