@@ -1029,7 +1029,7 @@ void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_
   hipLaunchKernelGGL(k_build_decode_tables, dim3(1), dim3(256), 0, s, d_code, d_dt, d_status);
 }
 
-struct DecLds {
+struct DecLds {  // K6 (side-car reconstruction): 4 waves, plain table
   alignas(16) uint32_t in[kDecWaves][kDecInWords + 4];
   alignas(16) uint16_t lut[1 << kDecLutBitsMax];
   uint32_t fcl[36];
@@ -1038,11 +1038,25 @@ struct DecLds {
   int status0;
 };
 
-__device__ __forceinline__ void dec_lds_load(DecLds& L, const DecTables* dt, int tid, int nthreads) {
-  const int lut_bits = dt->lut_bits;
-  const uint4* src = reinterpret_cast<const uint4*>(dt->lut);
-  uint4* dst = reinterpret_cast<uint4*>(L.lut);
-  for (int i = tid; i < ((1 << lut_bits) * 2 + 15) / 16; i += nthreads) dst[i] = src[i];
+// K7: the direct table is REPLICATED so that the 64 random lookups of a wave do not pile up on a few LDS banks
+// (PMC, 256 MiB uniform: 77 % of all LDS cycles of the un-replicated kernel were bank-conflict cycles).  The
+// table gets a fixed 32 KiB; with lut_bits index bits there is room for R = 2^(14 - lut_bits) copies, lane l uses
+// copy l % R:  9-bit codes (uniform bytes) -> 32 copies, every lane of a 32-lane LDS group in its own bank pair;
+// 12-bit tables -> 4 copies (skewed data hits few, mostly identical entries anyway: identical addresses broadcast).
+constexpr int kDec7Threads = 512;
+constexpr int kDec7Waves = kDec7Threads / kWave;
+constexpr int kDec7LutLog2 = 14;
+struct DecLds7 {
+  alignas(16) uint32_t in[kDec7Waves][kDecInWords + 4];
+  alignas(16) uint16_t lut[1 << kDec7LutLog2];
+  uint32_t fcl[36];
+  uint32_t sp[36];
+  uint16_t symbol[GHF_NSYM + 3];
+  int status0;
+};
+
+template <typename LT>
+__device__ __forceinline__ void dec_small_load(LT& L, const DecTables* dt, int tid, int nthreads) {
   if (tid < 36) {
     L.fcl[tid] = dt->fc_left[tid];
     L.sp[tid] = dt->start_pos[tid];
@@ -1050,9 +1064,29 @@ __device__ __forceinline__ void dec_lds_load(DecLds& L, const DecTables* dt, int
   for (int i = tid; i < GHF_NSYM; i += nthreads) L.symbol[i] = dt->symbol[i];
 }
 
+__device__ __forceinline__ void dec_lds_load(DecLds& L, const DecTables* dt, int tid, int nthreads) {
+  const int lut_bits = dt->lut_bits;
+  const uint4* src = reinterpret_cast<const uint4*>(dt->lut);
+  uint4* dst = reinterpret_cast<uint4*>(L.lut);
+  for (int i = tid; i < ((1 << lut_bits) * 2 + 15) / 16; i += nthreads) dst[i] = src[i];
+  dec_small_load(L, dt, tid, nthreads);
+}
+
+// replicated fill: entry idx, copy r at lut[(idx << rshift) | r]
+__device__ __forceinline__ void dec_lds_load7(DecLds7& L, const DecTables* dt, int tid, int nthreads) {
+  const int rshift = kDec7LutLog2 - dt->lut_bits;
+  uint32_t* dst = reinterpret_cast<uint32_t*>(L.lut);
+  for (int i = tid; i < (1 << (kDec7LutLog2 - 1)); i += nthreads) {  // two u16 slots per store
+    const uint32_t a = dt->lut[(2 * i) >> rshift], b = dt->lut[(2 * i + 1) >> rshift];
+    dst[i] = a | (b << 16);
+  }
+  dec_small_load(L, dt, tid, nthreads);
+}
+
 // codes longer than the direct table: the reference's linear extension (canonical_huff_encoder.cc:554-557).
 // returns sym | len << 16
-__device__ __forceinline__ uint32_t dec_long(const DecLds& L, uint32_t hi, int lut_bits, int max_len) {
+template <typename LT>
+__device__ __forceinline__ uint32_t dec_long(const LT& L, uint32_t hi, int lut_bits, int max_len) {
   int l = lut_bits + 1;
   while (l < max_len && hi < L.fcl[l]) ++l;
   const uint32_t k = L.sp[l] + ((hi - L.fcl[l]) >> (32 - l));
@@ -1078,10 +1112,15 @@ struct DecIn {
 // shift, the table lookup and an add.  K symbols are decoded between two refill checks -- the caller picks
 // K = 32 / max_len (<= 4), which keeps o + max_len <= 64 at every lookup -- and LONG says whether codes longer
 // than the direct table exist at all.  Returns an accumulator whose bit 8 is set when something is wrong.
-template <bool STAGED, int K, bool LONG>
-__device__ __forceinline__ uint32_t decode_segment(const DecLds& L, const DecIn<STAGED>& I, int lut_bits, int max_len,
+#if defined(GHF_EXP) && GHF_EXP == 1
+#define GHF_EXP_LUT(real, v) (((v) >> 24) | ((8u + ((v) >> 31)) << 9))   /* experiment: no table lookup */
+#else
+#define GHF_EXP_LUT(real, v) (real)
+#endif
+template <bool STAGED, int K, bool LONG, typename LT>
+__device__ __forceinline__ uint32_t decode_segment(const LT& L, const DecIn<STAGED>& I, int lut_bits, int max_len,
                                                    uint64_t pos, uint32_t cnt, bool valid, bool all_full, uint8_t* optr,
-                                                   int has_next, uint64_t expect_bits) {
+                                                   int has_next, uint64_t expect_bits, int rshift, uint32_t rep) {
   const int lsh = 32 - lut_bits;
   uint32_t widx = (uint32_t)(pos >> 5);
   uint32_t o = (uint32_t)(pos & 31u);
@@ -1091,16 +1130,25 @@ __device__ __forceinline__ uint32_t decode_segment(const DecLds& L, const DecIn<
   widx += 3;
   uint32_t bad_acc = 0;
 
+#if defined(GHF_EXP) && GHF_EXP == 3
+#define GHF_REFILL()                 \
+  if (o >= 32u) {                    \
+    W = (W << 32) | nextw;           \
+    o -= 32u;                        \
+    nextw = nextw * 2654435761u + widx++; \
+  }
+#else
 #define GHF_REFILL()                 \
   if (o >= 32u) {                    \
     W = (W << 32) | nextw;           \
     o -= 32u;                        \
     nextw = I.fetch(widx++);         \
   }
+#endif
 #define GHF_DEC(ENT)                                          \
   do {                                                        \
     const uint32_t v_ = (uint32_t)((W << o) >> 32);           \
-    ENT = L.lut[v_ >> lsh];                                   \
+    ENT = GHF_EXP_LUT(L.lut[((v_ >> lsh) << rshift) | rep], v_); \
     if (LONG && __builtin_expect((ENT >> 9) == 0, 0)) {       \
       const uint32_t r_ = dec_long(L, v_, lut_bits, max_len); \
       ENT = (r_ & 0x1FFu) | ((r_ >> 16) << 9);                \
@@ -1127,7 +1175,11 @@ __device__ __forceinline__ uint32_t decode_segment(const DecLds& L, const DecIn<
         const uint32_t hi = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0400u);
         wq[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
       }
+#if defined(GHF_EXP) && GHF_EXP == 2
+      if (valid && wq[0] == 0x12345678u && wq[1] == 0x9abcdef0u) *reinterpret_cast<uint4*>(optr + q * 16) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+#else
       if (valid) *reinterpret_cast<uint4*>(optr + q * 16) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+#endif
     }
   } else if (valid) {
     for (uint32_t i = 0; i < cnt; ++i) {
@@ -1202,25 +1254,27 @@ __device__ __forceinline__ void dec_span(const DecParams& P, uint64_t group, int
 
 constexpr int kDecVec = kDecInBytes / 1024;  // 16-byte vectors per lane that cover a staged span
 
-__global__ __launch_bounds__(kDecThreads, 5) void k_decode(DecParams P) {
-  __shared__ DecLds L;
+__global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
+  __shared__ DecLds7 L;
   const int tid = threadIdx.x;
   if (tid == 0) L.status0 = *P.status;  // one read per workgroup: the exit must be uniform
   __syncthreads();
   if (L.status0 != 0) return;
   const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
-  dec_lds_load(L, P.dt, tid, kDecThreads);
+  dec_lds_load7(L, P.dt, tid, kDec7Threads);
   __syncthreads();
+  const int rshift = kDec7LutLog2 - lut_bits;
+  const uint32_t rep = (uint32_t)tid & ((1u << rshift) - 1u);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar loop control
   const uint64_t ngroups = (P.n_segs + 63) >> 6;
-  const uint64_t gstride = (uint64_t)gridDim.x * kDecWaves;
+  const uint64_t gstride = (uint64_t)gridDim.x * kDec7Waves;
   const uint64_t stream_end_bit = P.stream_bytes * 8;
   const uint64_t full_bytes = P.stream_bytes & ~15ull;  // whole 16-byte vectors of the stream
   const bool out_aligned = (((uintptr_t)P.out) & 15u) == 0;
   uint32_t* in = L.in[wave];
   uint32_t bad_acc = 0;
-  uint64_t group = (uint64_t)blockIdx.x * kDecWaves + wave;
+  uint64_t group = (uint64_t)blockIdx.x * kDec7Waves + wave;
   if (group >= ngroups) return;
   const uint64_t glast = ngroups - 1;
   auto clampg = [&](uint64_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
@@ -1293,14 +1347,14 @@ __global__ __launch_bounds__(kDecThreads, 5) void k_decode(DecParams P) {
       if (staged) {
         DecIn<true> I{in, src, cur.span};
         // K = 32 / max_len symbols per refill check; LONG = codes beyond the direct table exist
-        if (max_len <= 8) bad_acc |= decode_segment<true, 4, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
-        else if (max_len <= 10) bad_acc |= decode_segment<true, 3, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
-        else if (max_len <= kDecLutBitsMax) bad_acc |= decode_segment<true, 2, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
-        else if (max_len <= 16) bad_acc |= decode_segment<true, 2, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
-        else bad_acc |= decode_segment<true, 1, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
+        if (max_len <= 8) bad_acc |= decode_segment<true, 4, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
+        else if (max_len <= 10) bad_acc |= decode_segment<true, 3, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
+        else if (max_len <= kDecLutBitsMax) bad_acc |= decode_segment<true, 2, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
+        else if (max_len <= 16) bad_acc |= decode_segment<true, 2, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
+        else bad_acc |= decode_segment<true, 1, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
       } else {
         DecIn<false> I{in, src, cur.span};
-        bad_acc |= decode_segment<false, 1, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect);
+        bad_acc |= decode_segment<false, 1, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
       }
     }
     // ---- rotate (all of these values have long arrived)
@@ -1308,15 +1362,19 @@ __global__ __launch_bounds__(kDecThreads, 5) void k_decode(DecParams P) {
     nxt.sbit = sbit2;
     nxt.nbit = nbit2;
   }
+#ifndef GHF_EXP
   if (bad_acc & 256u) latch_status(P.status, GHF_E_CORRUPT);  // a data symbol can never be 256
+#else
+  if (bad_acc == 0xFFFFFFFFu) latch_status(P.status, GHF_E_CORRUPT);
+#endif
 }
 
 void launch_decode(const DecParams& p, hipStream_t s) {
   const uint64_t groups = (p.n_segs + 63) / 64;
-  uint64_t blocks = (groups + kDecWaves - 1) / kDecWaves;
+  uint64_t blocks = (groups + kDec7Waves - 1) / kDec7Waves;
   if (blocks == 0) return;
-  if (blocks > 256 * 5) blocks = 256 * 5;  // persistent: 5 workgroups per CU fit the LDS
-  hipLaunchKernelGGL(k_decode, dim3((uint32_t)blocks), dim3(kDecThreads), 0, s, p);
+  if (blocks > 256 * 2) blocks = 256 * 2;  // persistent: 2 workgroups of 8 waves per CU fit the LDS
+  hipLaunchKernelGGL(k_decode, dim3((uint32_t)blocks), dim3(kDec7Threads), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
