@@ -121,49 +121,78 @@ def main():
 
     names = ["histogram", "allreduce", "build_code", "header", "plan", "allgather", "emit", "decode"]
     acc_ms = {k: 0.0 for k in names}
-    ev_steps = []
+    ev_log = []  # (name, start_event, end_event)
 
-    def step(record):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(9)] if record else None
+    # The one-wavefront code build (K2) is latency-bound (a strictly sequential heap on 1 of 256 CUs); every other
+    # kernel streams through HBM on the whole chip.  So consecutive steps are software-pipelined: while step i is
+    # bit-packed and decoded on the main stream, the histogram of step i+1 has already run and its code is being
+    # built on a side stream.  Every step still does all of its work; only the first K2 of a run is exposed.
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ctx_side = ghf.Context(local_rank)  # same device, queues on the side stream
+    hists = [torch.empty(ghf.NSYM, dtype=torch.int64, device="cuda") for _ in range(2)]
+    codes = [ctx.new_code(), ctx.new_code()]
+    last_rank = rank == world - 1
+    emit_flags = (ghf.EMIT_LAST if last_rank else 0) | (ghf.EMIT_REBASE if rank > 0 else 0)
 
-        def mark(i):
-            if ev is not None:
-                ev[i].record()
+    t_total = torch.empty(1, dtype=torch.int64, device="cuda")
+    t_end = torch.empty(2, dtype=torch.int64, device="cuda")
+    t_nbytes = torch.empty(1, dtype=torch.int64, device="cuda")
 
-        mark(0)
-        hist = ctx.histogram(d_in)
-        mark(1)
+    def timed(name, record, fn):
+        if not record:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        ev_log.append((name, e0, e1))
+        return r
+
+    def front(i, record):
+        """histogram (+ all-reduce) of step i on the main stream, code build on the side stream"""
+        h, c = hists[i & 1], codes[i & 1]
+        timed("histogram", record, lambda: ctx.histogram(d_in, out=h))
         if world > 1:
-            dist.all_reduce(hist[:256], op=dist.ReduceOp.SUM)
-        mark(2)
-        ctx.build_code(hist, d_code)
-        mark(3)
-        if rank == 0:
-            ctx.write_header(d_code, out)
-        mark(4)
-        total = ctx.encode_plan(d_in, d_code)
-        mark(5)
-        if world > 1:
-            totals = torch.empty(world, dtype=torch.int64, device="cuda")
-            dist.all_gather_into_tensor(totals, total)
-            before = totals[:rank].sum().reshape(1)
-            start_bit = sharded.header_bits_of(ctx, d_code) + before
-            flags = (ghf.EMIT_LAST if rank == world - 1 else 0) | (ghf.EMIT_REBASE if rank > 0 else 0)
-        else:
-            start_bit, flags = None, ghf.EMIT_LAST
-        mark(6)
-        end = ctx.encode_emit(d_in, d_code, out, start_bit=start_bit, flags=flags, index=index)
-        mark(7)
-        ctx.decode(out, bound, d_code, index, d_out=dec)
-        mark(8)
-        if ev is not None:
-            ev_steps.append(ev)
+            timed("allreduce", record, lambda: dist.all_reduce(h[:256], op=dist.ReduceOp.SUM))
+        hdone = torch.cuda.Event()
+        hdone.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(hdone)
+            timed("build_code", record, lambda: ctx_side.build_code(h, c))
+            kdone = torch.cuda.Event()
+            kdone.record(side)
+        return kdone
+
+    def run(K, record):
+        end = None
+        kdone = front(0, record)
+        for i in range(K):
+            c = codes[i & 1]
+            rec = record and (i % 4 == 1 or K <= 4)  # events on every 4th step: keeps the host ahead of the GPU
+            main.wait_event(kdone)
+            if rank == 0:
+                timed("header", rec, lambda: ctx.write_header(c, out))
+            total = timed("plan", rec, lambda: ctx.encode_plan(d_in, c, total=t_total))
+            if world > 1:
+                def gather():
+                    totals = torch.empty(world, dtype=torch.int64, device="cuda")
+                    dist.all_gather_into_tensor(totals, total)
+                    return sharded.header_bits_of(ctx, c) + totals[:rank].sum().reshape(1)
+                start_bit = timed("allgather", rec, gather)
+            else:
+                start_bit = None
+            if i + 1 < K:
+                kdone = front(i + 1, record and ((i + 1) % 4 == 1 or K <= 4))  # its K2 overlaps the emit + decode below
+            end = timed("emit", rec, lambda: ctx.encode_emit(d_in, c, out, start_bit=start_bit, flags=emit_flags, index=index, end=t_end))
+            timed("decode", rec, lambda: ctx.decode(out, bound, c, index, d_out=dec, nbytes=t_nbytes))
         return end
 
-    for _ in range(args.warmup):
-        end = step(False)
+    end = run(max(args.warmup, 1), False)
     torch.cuda.synchronize()
     ctx.sync()
+    ctx_side.sync()
     if not args.no_verify:
         assert bool((dec[:n] == d_in).all().item()), "round trip mismatch"
     comp_bytes = int(end[1].item())
@@ -172,28 +201,29 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    run(args.steps, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ctx.sync()  # raises if any stage latched an error
+    ctx_side.sync()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    for ev in ev_steps:
-        for i, k in enumerate(names):
-            acc_ms[k] += ev[i].elapsed_time(ev[i + 1])
-    stage_ms = {k: v / max(len(ev_steps), 1) for k, v in acc_ms.items()}
+    counts = {k: 0 for k in names}
+    for name, e0, e1 in ev_log:
+        acc_ms[name] += e0.elapsed_time(e1)
+        counts[name] += 1
+    stage_ms = {k: (acc_ms[k] / counts[k] if counts[k] else 0.0) for k in names}
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         total_in = n * world
         value = total_in * args.steps / elapsed / 1e9
-        enc_ms = sum(stage_ms[k] for k in names[:7])
+        enc_ms = sum(stage_ms[k] for k in names[:7])  # un-overlapped sum of the encode stages (latency of one buffer)
         # roofline of the dominant kernel (algorithmic bytes): emit reads N and writes the body,
         # decode reads C and writes N, histogram reads N
         body_bytes = comp_bytes if world == 1 else comp_bytes  # per-rank bytes written by emit
@@ -215,7 +245,8 @@ def main():
             "config": {"workload": "%d MiB %s bytes per GPU, encode (.crs2 bit-exact with the reference) + decode" % (args.mib, args.kind),
                        "baseline_config": "configs[1]" if (world == 1 and args.kind == "uniform" and args.mib == 256) else "configs[3]-style shard",
                        "bytes_per_gpu": n, "compressed_bytes_per_gpu": comp_bytes, "parallelism": "shard%d" % world,
-                       "collectives": "none" if world == 1 else "all_reduce(256 x i64) + all_gather(1 x i64) per step"},
+                       "collectives": "none" if world == 1 else "all_reduce(256 x i64) + all_gather(1 x i64) per step",
+                       "pipeline": "steps software-pipelined: the one-wave code build of step i+1 runs on a side stream under the emit+decode of step i"},
             "encode_GBps": round(n * world / (enc_ms * 1e-3) / 1e9, 3), "decode_GBps": round(n * world / (stage_ms["decode"] * 1e-3) / 1e9, 3),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -226,6 +257,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(d_in.cpu().numpy(), args.kind)
         print(json.dumps(res), flush=True)
     ctx.index_free(index)
+    ctx_side.close()
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -44,7 +44,12 @@ struct DecTables {
   uint32_t fc_left[36];    // first_code[len] << (32 - len), len = 1..max_len; 0xFFFFFFFF for len < min_len
   uint32_t start_pos[36];
   uint16_t symbol[GHF_NSYM + 3];
-  int32_t min_len, max_len, lut_bits, pad_;
+  int32_t min_len, max_len, lut_bits;
+  uint32_t pad_;
+  // work counters of k_decode, zeroed by k_build_decode_tables.  One word saturates at ~88 tickets/us (measured:
+  // a single counter made the 256 MiB decode 4.8x slower), so the workgroups are split into 16 classes
+  // (blockIdx % 16), each with its own counter on its own 128-byte line; class c owns the groups == c (mod 16).
+  uint32_t ticket[16 * 32];
   uint16_t lut[1 << kDecLutBitsMax];  // sym | len << 9 ; 0 = code longer than lut_bits
 };
 
@@ -68,7 +73,7 @@ struct EmitParams {
 struct DecParams {
   const uint8_t* stream;
   uint64_t stream_bytes;
-  const DecTables* dt;
+  DecTables* dt;
   const uint64_t* chunk_bit;
   const uint32_t* seg_bit;
   uint64_t n_symbols;

@@ -1009,6 +1009,7 @@ __global__ __launch_bounds__(256) void k_build_decode_tables(const ghf_code* __r
     dt->max_len = max_len;
     dt->lut_bits = lb;
   }
+  if (tid < 16) dt->ticket[tid * 32] = 0;
   __syncthreads();
   for (uint32_t idx = tid; idx < (1u << lb); idx += 256) {
     const uint32_t v = idx << (32 - lb);
@@ -1268,14 +1269,23 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar loop control
   const uint64_t ngroups = (P.n_segs + 63) >> 6;
-  const uint64_t gstride = (uint64_t)gridDim.x * kDec7Waves;
   const uint64_t stream_end_bit = P.stream_bytes * 8;
   const uint64_t full_bytes = P.stream_bytes & ~15ull;  // whole 16-byte vectors of the stream
   const bool out_aligned = (((uintptr_t)P.out) & 15u) == 0;
   uint32_t* in = L.in[wave];
   uint32_t bad_acc = 0;
-  uint64_t group = (uint64_t)blockIdx.x * kDec7Waves + wave;
+  // groups are handed out by a global ticket counter, not by a fixed stride: a wave that starts late (e.g. because
+  // another kernel occupied its CU) simply takes fewer groups instead of becoming the kernel's straggler
+  const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;  // every class needs at least one workgroup
+  const uint32_t cls = blockIdx.x % ncls;
+  auto ticket = [&]() -> uint64_t {
+    unsigned int t = 0;
+    if (lane == 0) t = atomicAdd(&P.dt->ticket[cls * 32], 1u);
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * ncls + cls;
+  };
+  uint64_t group = ticket();
   if (group >= ngroups) return;
+  uint64_t g1 = ticket(), g2 = ticket();  // the next two groups of this wave (their loads are issued ahead)
   const uint64_t glast = ngroups - 1;
   auto clampg = [&](uint64_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
 
@@ -1295,9 +1305,9 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
   dec_load_meta(P, group, lane, cur.sbit, cur.nbit);
   dec_span(P, group, lane, max_len, cur);
   issue(cur, R);
-  dec_load_meta(P, clampg(group + gstride), lane, nxt.sbit, nxt.nbit);
+  dec_load_meta(P, clampg(g1), lane, nxt.sbit, nxt.nbit);
 
-  for (; group < ngroups; group += gstride) {
+  for (; group < ngroups;) {
     // ---- 1. this group's span: registers -> LDS (big-endian words); everything behind it reads as zero
     wave_sync();
 #pragma unroll
@@ -1320,10 +1330,10 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
     }
     wave_sync();
     // ---- prefetch: span of the next group (its side-car entries arrived during the last decode), side-car of the one after
-    const uint64_t gn = clampg(group + gstride);
-    dec_span(P, gn, lane, max_len, nxt);
+    dec_span(P, clampg(g1), lane, max_len, nxt);
     issue(nxt, R);
-    dec_load_meta(P, clampg(group + 2 * gstride), lane, sbit2, nbit2);
+    dec_load_meta(P, clampg(g2), lane, sbit2, nbit2);
+    const uint64_t g3 = ticket();  // returns long before it is needed
     // ---- 2./3. decode
     const uint64_t seg0 = group * 64;
     const uint64_t seg = seg0 + lane;
@@ -1361,6 +1371,9 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
     cur = nxt;
     nxt.sbit = sbit2;
     nxt.nbit = nbit2;
+    group = g1;
+    g1 = g2;
+    g2 = g3;
   }
 #ifndef GHF_EXP
   if (bad_acc & 256u) latch_status(P.status, GHF_E_CORRUPT);  // a data symbol can never be 256

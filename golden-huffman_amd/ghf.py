@@ -212,9 +212,9 @@ class Context:
         return self.torch.from_numpy(a).to(self.device)
 
     # ---- stages --------------------------------------------------------------------------------
-    def histogram(self, d_in, n=None):
+    def histogram(self, d_in, n=None, out=None):
         n = d_in.numel() if n is None else n
-        hist = self.torch.empty(NSYM, dtype=self.torch.int64, device=self.device)
+        hist = self.torch.empty(NSYM, dtype=self.torch.int64, device=self.device) if out is None else out
         self._chk(self.L.ghf_histogram(self.h, d_in.data_ptr(), n, hist.data_ptr()), "ghf_histogram")
         return hist
 
@@ -226,15 +226,17 @@ class Context:
     def write_header(self, d_code, d_out):
         self._chk(self.L.ghf_write_header(self.h, d_code.data_ptr(), d_out.data_ptr(), d_out.numel()), "ghf_write_header")
 
-    def encode_plan(self, d_in, d_code, n=None):
+    def encode_plan(self, d_in, d_code, n=None, total=None):
         n = d_in.numel() if n is None else n
-        total = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
+        if total is None:
+            total = self.torch.empty(1, dtype=self.torch.int64, device=self.device)
         self._chk(self.L.ghf_encode_plan(self.h, d_in.data_ptr(), n, d_code.data_ptr(), total.data_ptr()), "ghf_encode_plan")
         return total
 
-    def encode_emit(self, d_in, d_code, d_out, start_bit=None, flags=EMIT_LAST, index=None, n=None):
+    def encode_emit(self, d_in, d_code, d_out, start_bit=None, flags=EMIT_LAST, index=None, n=None, end=None):
         n = d_in.numel() if n is None else n
-        end = self.torch.zeros(2, dtype=self.torch.int64, device=self.device)
+        if end is None:
+            end = self.torch.empty(2, dtype=self.torch.int64, device=self.device)
         self._chk(
             self.L.ghf_encode_emit(self.h, d_in.data_ptr(), n, d_code.data_ptr(),
                                    None if start_bit is None else start_bit.data_ptr(), flags, d_out.data_ptr(),
@@ -269,11 +271,12 @@ class Context:
         self._chk(self.L.ghf_decoded_size(self.h, d_stream.data_ptr(), stream_bytes, d_code.data_ptr(), C.byref(n)), "ghf_decoded_size")
         return n.value
 
-    def decode(self, d_stream, stream_bytes, d_code, index=None, d_out=None, cap=None):
+    def decode(self, d_stream, stream_bytes, d_code, index=None, d_out=None, cap=None, nbytes=None):
         """index=None: a stream without side-car (e.g. written by the reference); the library rebuilds it on the GPU."""
         if d_out is None:
             d_out = self.empty_u8(index.n_symbols if index is not None else cap)
-        nbytes = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
+        if nbytes is None:
+            nbytes = self.torch.empty(1, dtype=self.torch.int64, device=self.device)
         self._chk(
             self.L.ghf_decode(self.h, d_stream.data_ptr(), stream_bytes, d_code.data_ptr(),
                               None if index is None else C.byref(index), d_out.data_ptr(), d_out.numel(), nbytes.data_ptr()),
