@@ -4,7 +4,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('gpurun_out/pmc_%s/p*/**/*counter_collection.csv' % tag, recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].split('(')[0]
-        if not k.startswith('ghf::'): continue
+        if 'ghf::' not in k: continue
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k in sorted(acc):
     print(k)
