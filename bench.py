@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mib", type=int, default=256, help="input MiB per GPU")
     ap.add_argument("--kind", default="uniform", choices=["uniform", "zipf", "sym16"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 control flow with several ranks on ONE GPU (collectives staged via host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
@@ -98,12 +100,17 @@ def main():
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    if args.backend == "gloo":
+        local_rank = 0  # rehearsal mode: every rank drives cuda:0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     pkg = pkgload.load()
     ghf = pkg.ghf
     from golden_huffman_amd import sharded, synth
@@ -139,6 +146,24 @@ def main():
     t_total = torch.empty(1, dtype=torch.int64, device="cuda")
     t_end = torch.empty(2, dtype=torch.int64, device="cuda")
     t_nbytes = torch.empty(1, dtype=torch.int64, device="cuda")
+    t_totals = torch.empty(max(world, 1), dtype=torch.int64, device="cuda")
+    t_start = torch.empty(1, dtype=torch.int64, device="cuda")
+
+    def all_reduce_sum(t):
+        if args.backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            t.copy_(c)
+
+    def all_gather_1(out_t, t):
+        if args.backend == "nccl":
+            dist.all_gather_into_tensor(out_t, t)
+        else:
+            parts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(parts, t.cpu())
+            out_t.copy_(torch.cat(parts))
 
     def timed(name, record, fn):
         if not record:
@@ -155,7 +180,7 @@ def main():
         h, c = hists[i & 1], codes[i & 1]
         timed("histogram", record, lambda: ctx.histogram(d_in, out=h))
         if world > 1:
-            timed("allreduce", record, lambda: dist.all_reduce(h[:256], op=dist.ReduceOp.SUM))
+            timed("allreduce", record, lambda: all_reduce_sum(h[:256]))
         hdone = torch.cuda.Event()
         hdone.record(main)
         with torch.cuda.stream(side):
@@ -177,9 +202,8 @@ def main():
             total = timed("plan", rec, lambda: ctx.encode_plan(d_in, c, total=t_total))
             if world > 1:
                 def gather():
-                    totals = torch.empty(world, dtype=torch.int64, device="cuda")
-                    dist.all_gather_into_tensor(totals, total)
-                    return sharded.header_bits_of(ctx, c) + totals[:rank].sum().reshape(1)
+                    all_gather_1(t_totals, total)
+                    return ctx.shard_start_bit(c, t_totals, world, rank, out=t_start)
                 start_bit = timed("allgather", rec, gather)
             else:
                 start_bit = None
@@ -210,7 +234,7 @@ def main():
     ctx.sync()  # raises if any stage latched an error
     ctx_side.sync()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     counts = {k: 0 for k in names}

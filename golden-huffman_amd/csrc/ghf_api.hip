@@ -341,6 +341,15 @@ int ghf_encode_emit(ghf_ctx* c, const uint8_t* d_in, size_t n, const ghf_code* d
   return GHF_OK;
 }
 
+int ghf_shard_start_bit(ghf_ctx* c, const ghf_code* d_code, const uint64_t* d_totals, int world, int rank,
+                        uint64_t* d_start_bit) {
+  if (!c || !d_code || !d_totals || !d_start_bit || world < 1 || rank < 0 || rank >= world) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  launch_shard_start(d_code, d_totals, rank, d_start_bit, c->stream);
+  GHF_HIP(c, hipGetLastError());
+  return GHF_OK;
+}
+
 int ghf_compress(ghf_ctx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes,
                  ghf_code* d_code, const ghf_index* index) {
   if (!c || !d_out || (n && !d_in)) return GHF_E_INVAL;

@@ -115,6 +115,7 @@ void launch_emit(const EmitParams& p, hipStream_t s);
 void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_status, hipStream_t s);
 void launch_decode(const DecParams& p, hipStream_t s);
 void launch_store_u64(uint64_t* d_dst, const uint64_t* d_src_opt, uint64_t add, hipStream_t s);
+void launch_shard_start(const ghf_code* d_code, const uint64_t* d_totals, int rank, uint64_t* d_start_bit, hipStream_t s);
 
 }  // namespace ghf
 #endif

@@ -702,7 +702,11 @@ __device__ __forceinline__ void pack_pass(WaveOut& W, const Items<N>& it, bool a
       nb += l;
       if (nb >= 32u) {
         nb -= 32u;
+#if defined(GHF_EXP) && GHF_EXP == 6
+        w++;
+#else
         st[w++] = (uint32_t)(acc >> nb);
+#endif
       }
     }
   }
@@ -726,7 +730,11 @@ __device__ __forceinline__ void pack_pass(WaveOut& W, const Items<N>& it, bool a
       if (v.z) atomicOr(d + 2, v.z);
       if (v.w) atomicOr(d + 3, v.w);
     } else {
+#if defined(GHF_EXP) && GHF_EXP == 5
+      if (v.x == 0x12345678u && v.y == 0x9abcdef0u) *dst = v;
+#else
       *dst = v;
+#endif
     }
   }
   wave_sync();
@@ -775,7 +783,11 @@ __device__ __forceinline__ void lookup16(const typename E::T* tab, const uint4& 
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const uint32_t b = (vv[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+#if defined(GHF_EXP) && GHF_EXP == 7
+    e[j] = (typename E::T)((b << 8) | 8u);
+#else
     e[j] = tab[E::slot(b, (uint32_t)lane)];
+#endif
   }
 }
 
@@ -1294,7 +1306,7 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
 #pragma unroll
     for (int k = 0; k < kDecVec; ++k) {
       const uint64_t o = (uint64_t)k * 1024 + (uint64_t)lane * 16;
-      const bool ok = G.byte0 + o + 16 <= full_bytes;
+      const bool ok = o < G.span && G.byte0 + o + 16 <= full_bytes;  // lanes behind the span re-read byte 0 (an L2 hit)
       R[k] = *reinterpret_cast<const uint4*>(P.stream + (ok ? G.byte0 + o : 0));
     }
   };
@@ -1622,6 +1634,16 @@ void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_segs
 __global__ void k_store_u64(uint64_t* dst, const uint64_t* src, uint64_t add) { *dst = (src ? *src : 0ull) + add; }
 void launch_store_u64(uint64_t* d_dst, const uint64_t* d_src_opt, uint64_t add, hipStream_t s) {
   hipLaunchKernelGGL(k_store_u64, dim3(1), dim3(1), 0, s, d_dst, d_src_opt, add);
+}
+
+// multi-GPU: this rank's absolute start bit = header bits + body bits of all lower ranks
+__global__ void k_shard_start(const ghf_code* code, const uint64_t* totals, int rank, uint64_t* start_bit) {
+  uint64_t b = 8ull * (1040ull + 8ull * (uint64_t)code->max_len);
+  for (int r = 0; r < rank; ++r) b += totals[r];
+  *start_bit = b;
+}
+void launch_shard_start(const ghf_code* d_code, const uint64_t* d_totals, int rank, uint64_t* d_start_bit, hipStream_t s) {
+  hipLaunchKernelGGL(k_shard_start, dim3(1), dim3(1), 0, s, d_code, d_totals, rank, d_start_bit);
 }
 
 }  // namespace ghf

@@ -68,6 +68,7 @@ EXPORTS = [
     "ghf_host_free", "ghf_copy_h2d", "ghf_copy_d2h", "ghf_memset_d", "ghf_histogram", "ghf_build_code",
     "ghf_write_header", "ghf_header_bytes", "ghf_encode_plan", "ghf_encode_emit", "ghf_compress", "ghf_compress_bound",
     "ghf_chunk_symbols", "ghf_index_alloc", "ghf_index_free", "ghf_parse_header", "ghf_decode", "ghf_decoded_size",
+    "ghf_shard_start_bit",
 ]
 
 _lib = None
@@ -123,6 +124,7 @@ def lib():
     L.ghf_parse_header.argtypes = [vp, sz, C.POINTER(Code), C.POINTER(sz)]
     L.ghf_decode.argtypes = [vp, vp, sz, vp, C.POINTER(Index), vp, sz, vp]
     L.ghf_decoded_size.argtypes = [vp, vp, sz, vp, C.POINTER(u64)]
+    L.ghf_shard_start_bit.argtypes = [vp, vp, vp, i32, i32, vp]
     _lib = L
     return L
 
@@ -243,6 +245,12 @@ class Context:
                                    d_out.numel(), None if index is None else C.byref(index), end.data_ptr()),
             "ghf_encode_emit")
         return end
+
+    def shard_start_bit(self, d_code, d_totals, world, rank, out=None):
+        if out is None:
+            out = self.torch.empty(1, dtype=self.torch.int64, device=self.device)
+        self._chk(self.L.ghf_shard_start_bit(self.h, d_code.data_ptr(), d_totals.data_ptr(), world, rank, out.data_ptr()), "ghf_shard_start_bit")
+        return out
 
     def index_alloc(self, n):
         idx = Index()

@@ -44,8 +44,11 @@ def encode_sharded(be, dist, d_in, out=None, index=None, group=None):
         dist.all_gather_into_tensor(totals, total, group=group)
     else:
         totals = total.clone()
-    before = totals[:rank].sum().reshape(1) if rank > 0 else torch.zeros(1, dtype=torch.int64, device=total.device)
-    start_bit = header_bits_of(be, d_code) + before
+    if hasattr(be, "shard_start_bit"):
+        start_bit = be.shard_start_bit(d_code, totals, world, rank)  # one tiny kernel
+    else:
+        before = totals[:rank].sum().reshape(1) if rank > 0 else torch.zeros(1, dtype=torch.int64, device=total.device)
+        start_bit = header_bits_of(be, d_code) + before
     flags = 0
     if rank == world - 1:
         flags |= be.EMIT_LAST

@@ -128,6 +128,12 @@ int ghf_encode_plan(ghf_ctx* ctx, const uint8_t* d_in, size_t n, const ghf_code*
 int ghf_encode_emit(ghf_ctx* ctx, const uint8_t* d_in, size_t n, const ghf_code* d_code, const uint64_t* d_start_bit,
                     int flags, uint8_t* d_out, size_t cap, const ghf_index* index, uint64_t* d_end);
 
+/* Multi-GPU glue (no reference counterpart: the reference is single-stream): given the all-gathered per-rank body
+ * bit totals d_totals[world] (device), *d_start_bit = 8*(1040+8*max_len) + sum of d_totals[0..rank) -- the absolute
+ * stream bit at which rank `rank` must start emitting.  One tiny kernel, no host synchronisation. */
+int ghf_shard_start_bit(ghf_ctx* ctx, const ghf_code* d_code, const uint64_t* d_totals, int world, int rank,
+                        uint64_t* d_start_bit);
+
 /* ---- Compressor<CanonicalHuffEncoder<>>::compress(), include/compressor.h:62-73, in one call:
  *      histogram -> code -> header -> plan -> emit, no host synchronisation in between.
  *      d_out receives the complete .crs2 image; d_out_bytes (device u64) its size. */

@@ -107,3 +107,20 @@ def test_two_ranks_on_one_gpu(kind, n_total):
     ref = orc.compress(dg.make(kind, n_total, seed=9))
     got_stream = np.frombuffer(stream, dtype=np.uint8)
     assert got_stream.size == ref.size and np.array_equal(got_stream, ref)
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's N>1 control flow (offsets, flags, pipelining, index flags, round-trip check) with two ranks on
+    this one GPU: `--backend gloo` stages the two collectives through the host.  The RCCL run is the driver's."""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--backend", "gloo", "--mib", "32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "shard2"
