@@ -254,3 +254,35 @@ def test_full_size_256MiB_properties(env, kind):
     last = int(d_out[nb - 1].item())
     assert last & ((1 << pad) - 1) == (1 << pad) - 1
     ctx.index_free(idx)
+
+
+def test_random_sweep_sizes_and_alphabets(env):
+    """120 seeded cases across awkward sizes (around our 1 KiB tiles / 4 KiB chunks / 64-symbol segments) and
+    alphabets with many exact frequency ties: GPU .crs2 == oracle byte for byte; decode with side-car and, for
+    every third case, without."""
+    ghf, ctx, torch = env
+    sizes = [1, 2, 3, 15, 16, 17, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8192, 8193, 12289, 65535, 65536,
+             65537, 131071, 262145]
+    case = 0
+    for n in sizes:
+        for kind, mod in (("uniform", 0), ("zipf", 0), ("text", 0), ("uniform", 2), ("uniform", 3)):
+            case += 1
+            data = dg.make(kind, n, seed=5000 + case)
+            if mod:
+                data = (data % np.uint8(mod)).astype(np.uint8)
+            d_in = to_dev(torch, data)
+            idx = ctx.index_alloc(n)
+            d_out, nbytes, d_code = ctx.compress(d_in, index=idx)
+            ctx.sync()
+            nb = int(nbytes.item())
+            ref = orc.compress(data)
+            got = d_out[:nb].cpu().numpy()
+            assert nb == ref.size and np.array_equal(got, ref), (kind, mod, n, first_diff(got, ref))
+            back, _ = ctx.decode(d_out, nb, d_code, idx)
+            ctx.sync()
+            assert np.array_equal(back[:n].cpu().numpy(), data), (kind, mod, n)
+            ctx.index_free(idx)
+            if case % 3 == 0:
+                out2, n2 = ctx.decode(d_out, nb, d_code, None, cap=n + 64)
+                ctx.sync()
+                assert int(n2.item()) == n and np.array_equal(out2[:n].cpu().numpy(), data), (kind, mod, n, "foreign")
