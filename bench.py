@@ -141,7 +141,7 @@ def main():
     hists = [torch.empty(ghf.NSYM, dtype=torch.int64, device="cuda") for _ in range(2)]
     codes = [ctx.new_code(), ctx.new_code()]
     last_rank = rank == world - 1
-    emit_flags = (ghf.EMIT_LAST if last_rank else 0) | (ghf.EMIT_REBASE if rank > 0 else 0)
+    emit_flags = (ghf.EMIT_LAST if last_rank else 0) | (ghf.EMIT_REBASE if rank > 0 else ghf.EMIT_HEADER)  # rank 0 writes the header
 
     t_total = torch.empty(1, dtype=torch.int64, device="cuda")
     t_end = torch.empty(2, dtype=torch.int64, device="cuda")
@@ -197,8 +197,6 @@ def main():
             c = codes[i & 1]
             rec = record and (i % 4 == 1 or K <= 4)  # events on every 4th step: keeps the host ahead of the GPU
             main.wait_event(kdone)
-            if rank == 0:
-                timed("header", rec, lambda: ctx.write_header(c, out))
             total = timed("plan", rec, lambda: ctx.encode_plan(d_in, c, total=t_total))
             if world > 1:
                 def gather():

@@ -311,6 +311,8 @@ int ghf_encode_emit(ghf_ctx* c, const uint8_t* d_in, size_t n, const ghf_code* d
                     int flags, uint8_t* d_out, size_t cap, const ghf_index* index, uint64_t* d_end) {
   if (!c || !d_code || !d_out || (n && !d_in)) return GHF_E_INVAL;
   if (!aligned16(d_out)) return fail(c, GHF_E_INVAL, "d_out must be 16-byte aligned");
+  if ((flags & GHF_EMIT_HEADER) && (flags & GHF_EMIT_REBASE))
+    return fail(c, GHF_E_INVAL, "GHF_EMIT_HEADER is for the buffer that starts at stream byte 0 (rank 0 / single GPU)");
   if (c->plan_in != d_in || c->plan_n != n || c->plan_code != d_code)
     return fail(c, GHF_E_INVAL, "ghf_encode_emit: call ghf_encode_plan on the same (d_in, n, d_code) first");
   GHF_HIP(c, hipSetDevice(c->device));
@@ -359,9 +361,9 @@ int ghf_compress(ghf_ctx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, size
   int rc;
   if ((rc = ghf_histogram(c, d_in, n, c->d_hist))) return rc;   // compressor.h:63
   if ((rc = ghf_build_code(c, c->d_hist, code))) return rc;     // compressor.h:64
-  if ((rc = ghf_write_header(c, code, d_out, cap))) return rc;  // compressor.h:70
   if ((rc = ghf_encode_plan(c, d_in, n, code, c->d_u64))) return rc;
-  if ((rc = ghf_encode_emit(c, d_in, n, code, nullptr, GHF_EMIT_LAST, d_out, cap, index, c->d_u64 + 1))) return rc;  // :72
+  // compressor.h:70 + :72 -- the header rides along with the emit launches
+  if ((rc = ghf_encode_emit(c, d_in, n, code, nullptr, GHF_EMIT_LAST | GHF_EMIT_HEADER, d_out, cap, index, c->d_u64 + 1))) return rc;
   if (d_out_bytes) {
     launch_store_u64(d_out_bytes, c->d_u64 + 2, 0, c->stream);
     GHF_HIP(c, hipGetLastError());
@@ -608,8 +610,9 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
   p.no_end_mark = (index->flags & GHF_INDEX_NO_END_MARK) ? 1u : 0u;
   p.out = d_out;
   p.status = c->d_status;
+  p.out_bytes = d_out_bytes;
   launch_decode(p, c->stream);
-  if (d_out_bytes) launch_store_u64(d_out_bytes, nullptr, index->n_symbols, c->stream);
+  if (d_out_bytes && index->n_symbols == 0) launch_store_u64(d_out_bytes, nullptr, 0, c->stream);  // no decode launch then
   GHF_HIP(c, hipGetLastError());
   return GHF_OK;
 }

@@ -81,6 +81,7 @@ struct DecParams {
   uint32_t chunk_log2;
   uint32_t no_end_mark;  // the last symbol is not followed by the end mark (a shard that is not the stream's last)
   uint8_t* out;
+  uint64_t* out_bytes;  // optional device u64 <- n_symbols
   int* status;
 };
 

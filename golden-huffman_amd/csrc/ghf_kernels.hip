@@ -466,6 +466,16 @@ void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, 
 // a5: header.  u32 big-endian: 257, symbol_[0..256], min_len, max_len, (start_pos[i], first_code[i]) i=1..max_len
 // (canonical_huff_encoder.cc:223-237, utils/include/buffer.h:261-268)
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t header_word(const ghf_code* code, int w, int max_len) {
+  if (w == 0) return GHF_NSYM;
+  if (w <= GHF_NSYM) return code->symbol[w - 1];
+  if (w == GHF_NSYM + 1) return (uint32_t)code->min_len;
+  if (w == GHF_NSYM + 2) return (uint32_t)max_len;
+  const int k = w - (GHF_NSYM + 3);
+  const int i = 1 + (k >> 1);
+  return (k & 1) ? code->first_code[i] : code->start_pos[i];
+}
+
 __global__ __launch_bounds__(256) void k_write_header(const ghf_code* __restrict__ code, uint8_t* __restrict__ out,
                                                       uint64_t cap, int* __restrict__ status) {
   const int max_len = code->max_len;
@@ -476,19 +486,7 @@ __global__ __launch_bounds__(256) void k_write_header(const ghf_code* __restrict
     return;
   }
   uint32_t* o = reinterpret_cast<uint32_t*>(out);
-  for (int w = threadIdx.x; w < nwords; w += blockDim.x) {
-    uint32_t v;
-    if (w == 0) v = GHF_NSYM;
-    else if (w <= GHF_NSYM) v = code->symbol[w - 1];
-    else if (w == GHF_NSYM + 1) v = (uint32_t)code->min_len;
-    else if (w == GHF_NSYM + 2) v = (uint32_t)max_len;
-    else {
-      const int k = w - (GHF_NSYM + 3);
-      const int i = 1 + (k >> 1);
-      v = (k & 1) ? code->first_code[i] : code->start_pos[i];
-    }
-    o[w] = bswap32(v);
-  }
+  for (int w = threadIdx.x; w < nwords; w += blockDim.x) o[w] = bswap32(header_word(code, w, max_len));
 }
 
 void launch_write_header(const ghf_code* d_code, uint8_t* d_out, uint64_t cap, int* d_status, hipStream_t s) {
@@ -614,28 +612,22 @@ struct E64 {  // codes up to 32 bits
   static constexpr uint32_t kRep = 16;
 };
 
-// Three variants of the same kernel, picked by max_len (device side: the host cannot know it without a round trip):
+// Two variants of the same kernel, picked by max_len (device side: the host cannot know it without a round trip;
+// both are launched, the one that does not apply exits at once):
 //   PairMode  max_len <= 16 : two neighbouring symbols are fused into one <= 32-bit item right after the table
 //                             lookup, which halves the serial work of the bit packer (every BASELINE config)
-//   MidMode   17..24        : one item per symbol, 32-bit table entries
-//   WideMode  25..32        : one item per symbol, 64-bit table entries
+//   WideMode  17..32        : one item per symbol, 64-bit table entries
 struct PairMode {
   typedef E32 E;
   static constexpr int N = 8;
   static constexpr int kMinWaves = 6;  // <= 80 VGPRs: three 8-wave workgroups per CU (LDS allows exactly three)
   static __device__ __forceinline__ bool applies(int max_len) { return max_len <= 16; }
 };
-struct MidMode {
-  typedef E32 E;
-  static constexpr int N = 16;
-  static constexpr int kMinWaves = 4;
-  static __device__ __forceinline__ bool applies(int max_len) { return max_len > 16 && max_len <= 24; }
-};
 struct WideMode {
   typedef E64 E;
   static constexpr int N = 16;
   static constexpr int kMinWaves = 4;
-  static __device__ __forceinline__ bool applies(int max_len) { return max_len > 24; }
+  static __device__ __forceinline__ bool applies(int max_len) { return max_len > 16; }
 };
 
 template <int N>
@@ -974,15 +966,20 @@ __global__ __launch_bounds__(256) void k_emit_prep(EmitParams P) {
       uint8_t* u = P.out + (((end >> 7) << 4) - origin_byte);
       *reinterpret_cast<uint4*>(u) = make_uint4(0, 0, 0, 0);
     }
+  } else if ((P.flags & GHF_EMIT_HEADER) && !(P.flags & GHF_EMIT_REBASE)) {
+    // a5, canonical_huff_encoder.cc:210-242: the header words in front of the body.  The first code sits right
+    // behind the header (start_bit is its end), and chunk 0's thread above only clears bytes from start_bit on.
+    const int w = (int)(i - P.nchunks - 1);
+    const int nwords = 1 + GHF_NSYM + 2 + 2 * max_len;
+    if (w < nwords && (uint64_t)(w + 1) * 32 <= start_bit) reinterpret_cast<uint32_t*>(P.out)[w] = bswap32(header_word(P.code, w, max_len));
   }
 }
 
 void launch_emit(const EmitParams& p, hipStream_t s) {
-  const uint32_t prep_blocks = (p.nchunks + 1 + 255) / 256;
+  const uint32_t prep_blocks = (p.nchunks + 1 + ((p.flags & GHF_EMIT_HEADER) ? 1 + GHF_NSYM + 2 + 64 : 0) + 255) / 256;
   hipLaunchKernelGGL(k_emit_prep, dim3(prep_blocks), dim3(256), 0, s, p);
   const uint32_t blocks = (p.nchunks + kEmitWaves - 1) / kEmitWaves;
   hipLaunchKernelGGL(k_emit<PairMode>, dim3(blocks), dim3(kEmitThreads), 0, s, p);
-  hipLaunchKernelGGL(k_emit<MidMode>, dim3(blocks), dim3(kEmitThreads), 0, s, p);
   hipLaunchKernelGGL(k_emit<WideMode>, dim3(blocks), dim3(kEmitThreads), 0, s, p);
 }
 
@@ -1278,6 +1275,7 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
   __syncthreads();
   const int rshift = kDec7LutLog2 - lut_bits;
   const uint32_t rep = (uint32_t)tid & ((1u << rshift) - 1u);
+  if (blockIdx.x == 0 && tid == 0 && P.out_bytes) *P.out_bytes = P.n_symbols;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar loop control
   const uint64_t ngroups = (P.n_segs + 63) >> 6;

@@ -7,6 +7,7 @@ import os
 NSYM = 257
 EMIT_LAST = 1
 EMIT_REBASE = 2
+EMIT_HEADER = 4
 INDEX_NO_END_MARK = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -155,6 +156,7 @@ class Context:
 
     EMIT_LAST = EMIT_LAST
     EMIT_REBASE = EMIT_REBASE
+    EMIT_HEADER = EMIT_HEADER
     compress_bound = staticmethod(compress_bound)
 
     def __init__(self, device=0):

@@ -59,7 +59,10 @@ def encode_sharded(be, dist, d_in, out=None, index=None, group=None):
     if index is not None:
         index.flags = 0 if rank == world - 1 else 1  # GHF_INDEX_NO_END_MARK: this shard is not followed by the end mark
     if rank == 0:
-        be.write_header(d_code, out)  # a5
+        if hasattr(be, "EMIT_HEADER"):
+            flags |= be.EMIT_HEADER  # a5: the header rides along with the emit launches
+        else:
+            be.write_header(d_code, out)
     end = be.encode_emit(d_in, d_code, out, start_bit=start_bit, flags=flags, index=index)  # K5
     return {"out": out, "start_bit": start_bit, "end": end, "code": d_code, "totals": totals, "n": n}
 

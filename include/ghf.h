@@ -115,7 +115,8 @@ size_t ghf_header_bytes(int max_len); /* 1040 + 8*max_len */
  * emit: every wave packs one chunk MSB-first into the pre-sized output.
  *   d_start_bit : absolute stream bit of this buffer's first code (device u64); NULL = right after the
  *                 header, i.e. 8*(1040+8*max_len)  (single-GPU case).
- *   flags       : GHF_EMIT_LAST   append the end mark (symbol 256) and pad with 1-bits to a byte,
+ *   flags       : GHF_EMIT_HEADER the header goes out with the same launches (saves the separate ghf_write_header),
+ *                 GHF_EMIT_LAST   append the end mark (symbol 256) and pad with 1-bits to a byte,
  *                 GHF_EMIT_REBASE d_out[0] is stream byte 16*(start_bit/128) instead of stream byte 0
  *                                 (shard-local output buffers of the multi-GPU path).
  *   d_index     : optional side-car for ghf_decode (NULL = none).
@@ -124,6 +125,7 @@ size_t ghf_header_bytes(int max_len); /* 1040 + 8*max_len */
  * Both must be called with the same (d_in, n, d_code); plan first. */
 #define GHF_EMIT_LAST 1
 #define GHF_EMIT_REBASE 2
+#define GHF_EMIT_HEADER 4 /* also write the .crs2 header at d_out[0..) (same bytes as ghf_write_header; not with REBASE) */
 int ghf_encode_plan(ghf_ctx* ctx, const uint8_t* d_in, size_t n, const ghf_code* d_code, uint64_t* d_total_bits);
 int ghf_encode_emit(ghf_ctx* ctx, const uint8_t* d_in, size_t n, const ghf_code* d_code, const uint64_t* d_start_bit,
                     int flags, uint8_t* d_out, size_t cap, const ghf_index* index, uint64_t* d_end);
