@@ -29,6 +29,7 @@ struct ghf_ctx {
   uint64_t plan_n = 0;
   const ghf_code* plan_code = nullptr;
   uint64_t* d_hist = nullptr;   // [257]
+  uint64_t* d_hist_acc = nullptr;  // K1's replicated totals + arrival counter, zero between launches
   ghf_code* d_code = nullptr;   // scratch tables for ghf_compress
   DecTables* d_dt = nullptr;
   uint64_t* d_u64 = nullptr;    // [8] scratch scalars: 0 total_bits, 1..2 end, 3 n_symbols, 4 eof_sub, 5 changed
@@ -134,6 +135,8 @@ int ghf_ctx_create(int device, ghf_ctx** out) {
   GHF_STEP(hipMalloc(&c->d_status, sizeof(int)));
   GHF_STEP(hipHostMalloc(&c->h_status, sizeof(int), hipHostMallocDefault));
   GHF_STEP(hipMalloc(&c->d_hist, GHF_NSYM * sizeof(uint64_t)));
+  GHF_STEP(hipMalloc(&c->d_hist_acc, kHistAccWords * sizeof(uint64_t)));
+  GHF_STEP(hipMemset(c->d_hist_acc, 0, kHistAccWords * sizeof(uint64_t)));
   GHF_STEP(hipMalloc(&c->d_code, sizeof(ghf_code)));
   GHF_STEP(hipMalloc(&c->d_dt, sizeof(DecTables)));
   GHF_STEP(hipMalloc(&c->d_u64, 8 * sizeof(uint64_t)));
@@ -159,6 +162,7 @@ int ghf_ctx_destroy(ghf_ctx* c) {
   if (c->d_chunk_hist) (void)hipFree(c->d_chunk_hist);
   if (c->d_chunk_off) (void)hipFree(c->d_chunk_off);
   if (c->d_hist) (void)hipFree(c->d_hist);
+  if (c->d_hist_acc) (void)hipFree(c->d_hist_acc);
   if (c->d_code) (void)hipFree(c->d_code);
   if (c->d_dt) (void)hipFree(c->d_dt);
   if (c->d_u64) (void)hipFree(c->d_u64);
@@ -194,6 +198,7 @@ int ghf_clear_status(ghf_ctx* c) {
   if (!c) return GHF_E_INVAL;
   GHF_HIP(c, hipSetDevice(c->device));
   GHF_HIP(c, hipMemsetAsync(c->d_status, 0, sizeof(int), c->stream));
+  GHF_HIP(c, hipMemsetAsync(c->d_hist_acc, 0, kHistAccWords * sizeof(uint64_t), c->stream));  // in case a launch died half-way
   c->err.clear();
   return GHF_OK;
 }
@@ -265,7 +270,7 @@ int ghf_histogram(ghf_ctx* c, const uint8_t* d_in, size_t n, uint64_t* d_hist) {
   const size_t nchunks = (n + ((size_t)1 << cl) - 1) >> cl;
   int rc = ensure_ws(c, nchunks);
   if (rc) return rc;
-  launch_histogram(d_in, n, cl, (uint32_t)nchunks, c->d_chunk_hist, d_hist, c->stream);
+  launch_histogram(d_in, n, cl, (uint32_t)nchunks, c->d_chunk_hist, d_hist, c->d_hist_acc, c->stream);
   GHF_HIP(c, hipGetLastError());
   c->hist_in = d_in;
   c->hist_n = n;

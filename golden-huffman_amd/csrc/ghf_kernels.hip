@@ -57,9 +57,11 @@ __device__ __forceinline__ void hist_vec(uint32_t* lh, uint32_t rep, const uint4
 __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __restrict__ in, uint64_t n,
                                                             uint32_t chunk_log2, uint32_t nchunks,
                                                             uint32_t* __restrict__ chunk_hist,
-                                                            unsigned long long* __restrict__ hist) {
+                                                            unsigned long long* __restrict__ hist,
+                                                            unsigned long long* __restrict__ acc /* [32][256] + done */) {
   static_assert(kHistRep == 32, "replica index is lane % 32");
   __shared__ uint32_t lh[256 * kHistRep];
+  __shared__ bool s_last;
   const uint32_t tid = threadIdx.x;
   const uint32_t rep = tid & 31u;
   for (uint32_t i = tid; i < 256 * kHistRep; i += kHistThreads) lh[i] = 0;
@@ -129,13 +131,41 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
     if (tail0 + tid < len) atomicAdd(&lh[((uint32_t)p[tail0 + tid] << 5) | rep], 1u);
     finish_chunk(c);
   }
-  if (total) atomicAdd(&hist[tid], total);
-  if (blockIdx.x == 0 && tid == 0) hist[256] = 1;  // include/encoder.h:128 end-of-stream mark counts once
+  // Global totals.  1024 workgroups adding into the same 256 words would serialise at the memory side (one word
+  // takes ~12 ns per atomic), so each workgroup adds into one of 32 replicas; the LAST workgroup to finish sums
+  // the replicas into the caller's histogram and leaves them zeroed for the next launch (no memset, no extra
+  // kernel).  Hand-off: every wave drains its atomics, workgroup barrier, one lane takes a ticket; the last
+  // workgroup acquires and reads the replicas with agent-scope (L1-bypassing) loads.
+  unsigned long long* rep_base = acc + (uint64_t)(blockIdx.x & 31u) * 256;
+  if (total) atomicAdd(&rep_base[tid], total);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    // no release fence: the only data handed over are the atomic adds above, which execute at the memory side
+    // and were acknowledged (vmcnt drained) before the barrier; the plain chunk_hist stores are for later kernels
+    const unsigned long long t = atomicAdd(&acc[32 * 256], 1ull);
+    s_last = (t + 1 == gridDim.x);
+    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (s_last) {
+    unsigned long long sum = 0;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      sum += __hip_atomic_load(&acc[r * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&acc[r * 256 + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    hist[tid] = sum;
+    if (tid == 0) {
+      hist[256] = 1;  // include/encoder.h:128 end-of-stream mark counts once
+      __hip_atomic_store(&acc[32 * 256], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, uint32_t* d_chunk_hist,
-                      uint64_t* d_hist, hipStream_t s) {
-  (void)hipMemsetAsync(d_hist, 0, GHF_NSYM * sizeof(uint64_t), s);
+                      uint64_t* d_hist, uint64_t* d_acc, hipStream_t s) {
   // one resident round of workgroups, 4 per CU: measured faster than the 5 the LDS would allow (2 GiB stream:
   // 5.55 TB/s at 1024 workgroups vs 4.95 TB/s at 1280 -- the fifth workgroup only adds L2/LDS pressure)
   static int ncu = 0;
@@ -149,7 +179,7 @@ void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint
   if (grid > nchunks) grid = nchunks;
   if (grid == 0) grid = 1;
   hipLaunchKernelGGL(k_histogram, dim3(grid), dim3(kHistThreads), 0, s, d_in, n, chunk_log2, nchunks, d_chunk_hist,
-                     reinterpret_cast<unsigned long long*>(d_hist));
+                     reinterpret_cast<unsigned long long*>(d_hist), reinterpret_cast<unsigned long long*>(d_acc));
 }
 
 // ------------------------------------------------------------------------------------------------
