@@ -106,7 +106,9 @@ void launch_sync_pass(const SyncParams& p, hipStream_t s);
 void launch_sync_counts(const SyncParams& p, uint64_t* d_total, hipStream_t s);
 void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_segs, uint32_t chunk_log2, uint64_t* d_chunk_bit,
                        uint32_t* d_seg_bit, hipStream_t s);
-constexpr size_t kHistAccWords = 32 * 256 + 8;  // 32 replicas of the 256 totals + the arrival counter (kept zero between launches)
+// K1 scratch, all zero between launches: 32 replicas of the 256 totals, the arrival counter (word 8192), 16 ticket
+// counters (word 8208 + 16 k, one 128-byte line each)
+constexpr size_t kHistAccWords = 32 * 256 + 16 + 16 * 16;
 void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, uint32_t* d_chunk_hist,
                       uint64_t* d_hist, uint64_t* d_acc, hipStream_t s);
 void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, hipStream_t s);

@@ -70,10 +70,13 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
   unsigned long long total = 0;
   const uint64_t chunk = 1ull << chunk_log2;
 
+  __shared__ uint32_t s_tick;
   // end of a chunk: thread t sums the 32 replicas of bin t (rotated start: 32 lanes on 32 banks); the counters
-  // keep running, the chunk's count is the difference to the previous sum (mod 2^32)
-  auto finish_chunk = [&](uint32_t c) {
+  // keep running, the chunk's count is the difference to the previous sum (mod 2^32).  Returns the ticket word
+  // thread 0 posted before the call (how the workgroup learns its chunk after next without an extra barrier).
+  auto finish_chunk = [&](uint32_t c) -> uint32_t {
     __syncthreads();
+    const uint32_t posted = s_tick;
     uint32_t s = 0;
 #pragma unroll
     for (uint32_t j = 0; j < kHistRep; ++j) s += lh[(tid << 5) | ((j + tid) & 31u)];
@@ -82,39 +85,60 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
     chunk_hist[(uint64_t)c * 256 + tid] = cnt;
     total += cnt;
     __syncthreads();
+    return posted;
   };
 
-  // ---- fast phase: this workgroup's full, 16-byte aligned chunks as ONE stream of 16-byte vectors per thread.
-  // Four loads per lane are always in flight (A/B and C/D alternate, no register copies), including across the
-  // chunk boundary: the first vectors of the next chunk are already requested while this chunk is being reduced.
+  // ---- fast phase: full, 16-byte aligned chunks, handed out by ticket counters (16 classes of workgroups, one
+  // counter per class on its own 128-byte line: a single counter saturates at ~88 tickets/us).  Dynamic hand-out
+  // keeps a late or slow workgroup from becoming the kernel's straggler.  Per thread the vectors of consecutive
+  // chunks form ONE stream: four 16-byte loads are always in flight (A/B and C/D alternate, no register copies),
+  // also across the chunk boundary -- the next chunk's first vectors are requested while this one is reduced.
   const uint32_t vlog = chunk_log2 - 12;  // vectors per thread per chunk = 2^vlog (256 threads x 16 B = 4 KiB)
   const uint32_t nfullchunks = (uint32_t)(n >> chunk_log2);
-  uint32_t mdone = 0;  // how many of this workgroup's chunks the fast phase covered
-  if (vlog >= 2 && (((uintptr_t)in) & 15u) == 0 && blockIdx.x < nfullchunks) {
-    const uint32_t mfull = (nfullchunks - blockIdx.x + gridDim.x - 1) / gridDim.x;
-    const uint64_t F = (uint64_t)mfull << vlog;
-    const uint64_t vmask = (1ull << vlog) - 1;
-    auto vptr = [&](uint64_t f) -> const uint4* {
-      if (f >= F) f = F - 1;  // clamped: the very last prefetches are redundant, never out of bounds
-      const uint64_t c = blockIdx.x + (f >> vlog) * gridDim.x;
-      return reinterpret_cast<const uint4*>(in + (c << chunk_log2)) + (f & vmask) * kHistThreads + tid;
+  const bool fast = vlog >= 2 && (((uintptr_t)in) & 15u) == 0 && nfullchunks > 0;
+  if (fast) {
+    const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;
+    const uint32_t cls = blockIdx.x % ncls;
+    unsigned long long* tick = acc + 32 * 256 + 16 + cls * 16;
+    auto draw = [&]() -> uint32_t { return (uint32_t)atomicAdd(tick, 1ull) * ncls + cls; };  // thread 0 only
+    if (tid == 0) s_tick = draw();
+    __syncthreads();
+    uint32_t cur = s_tick;
+    __syncthreads();
+    if (tid == 0) s_tick = draw();
+    __syncthreads();
+    uint32_t nxt = s_tick;
+    __syncthreads();
+    const uint32_t V = 1u << vlog;
+    auto vptr = [&](uint32_t c, uint32_t j) -> const uint4* {
+      if (c >= nfullchunks) c = nfullchunks - 1;  // past the end: redundant, harmless loads
+      return reinterpret_cast<const uint4*>(in + ((uint64_t)c << chunk_log2)) + (uint64_t)j * kHistThreads + tid;
     };
-    uint4 A = *vptr(0), B = *vptr(1);
-    for (uint64_t f = 0; f < F; f += 4) {
-      const uint4 C = *vptr(f + 2), D = *vptr(f + 3);
-      hist_vec(lh, rep, A);
-      hist_vec(lh, rep, B);
-      A = *vptr(f + 4);
-      B = *vptr(f + 5);
-      hist_vec(lh, rep, C);
-      hist_vec(lh, rep, D);
-      if (((f + 4) & vmask) == 0) finish_chunk(blockIdx.x + (uint32_t)(f >> vlog) * gridDim.x);
+    uint4 A = *vptr(cur, 0), B = *vptr(cur, 1);
+    while (cur < nfullchunks) {
+      uint32_t t_next = 0;
+      if (tid == 0) t_next = draw();  // the chunk after next; the atomic returns long before it is needed
+      for (uint32_t j = 0; j < V; j += 4) {
+        const uint4 C = *vptr(cur, j + 2), D = *vptr(cur, j + 3);
+        hist_vec(lh, rep, A);
+        hist_vec(lh, rep, B);
+        const bool more = j + 4 < V;
+        A = *vptr(more ? cur : nxt, more ? j + 4 : 0);
+        B = *vptr(more ? cur : nxt, more ? j + 5 : 1);
+        hist_vec(lh, rep, C);
+        hist_vec(lh, rep, D);
+      }
+      if (tid == 0) s_tick = t_next;
+      const uint32_t posted = finish_chunk(cur);
+      cur = nxt;
+      nxt = posted;
     }
-    mdone = mfull;
   }
 
-  // ---- generic phase: small chunks, unaligned input, the ragged last chunk
-  for (uint32_t c = blockIdx.x + mdone * gridDim.x; c < nchunks; c += gridDim.x) {
+  // ---- generic phase: small chunks, unaligned input (all chunks, static), or just the ragged last chunk
+  const uint32_t g0 = fast ? (blockIdx.x == 0 ? nfullchunks : nchunks) : blockIdx.x;
+  const uint32_t gstep = fast ? nchunks : gridDim.x;
+  for (uint32_t c = g0; c < nchunks; c += gstep) {
     const uint64_t base = (uint64_t)c << chunk_log2;
     const uint64_t len = (n - base < chunk) ? (n - base) : chunk;
     const uint8_t* p = in + base;
@@ -129,7 +153,7 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
     }
     const uint64_t tail0 = head + (nvec << 4);
     if (tail0 + tid < len) atomicAdd(&lh[((uint32_t)p[tail0 + tid] << 5) | rep], 1u);
-    finish_chunk(c);
+    (void)finish_chunk(c);
   }
   // Global totals.  1024 workgroups adding into the same 256 words would serialise at the memory side (one word
   // takes ~12 ns per atomic), so each workgroup adds into one of 32 replicas; the LAST workgroup to finish sums
@@ -157,6 +181,7 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
       __hip_atomic_store(&acc[r * 256 + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     hist[tid] = sum;
+    if (tid < 16) __hip_atomic_store(&acc[32 * 256 + 16 + tid * 16], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) {
       hist[256] = 1;  // include/encoder.h:128 end-of-stream mark counts once
       __hip_atomic_store(&acc[32 * 256], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
