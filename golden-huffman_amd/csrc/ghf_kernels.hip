@@ -29,13 +29,18 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ void latch_status(int* st, int code) { atomicCAS(st, 0, code); }
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, 64);
-    if (lane >= d) v += t;
-  }
-  return v;
+// inclusive prefix sum over the 64 lanes in six v_add_u32_dpp: row_shr 1/2/4/8 inside the rows of 16, then
+// row_bcast:15 and row_bcast:31 carry the row totals across (the classic gfx9 wave64 scan; no LDS traffic,
+// unlike __shfl_up, which lowers to ds_bpermute_b32 and costs an LDS round trip per step)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int /*lane*/) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2 and 3
+  return (uint32_t)x;
 }
 
 // ------------------------------------------------------------------------------------------------
