@@ -260,6 +260,16 @@ def main():
                 traffic = json.load(open(tf)).get("%s_%s_%dMiB" % (dom, args.kind, args.mib))
             except Exception:
                 traffic = None
+        # context for the roofline: what a plain device-to-device copy of the same bytes reaches on this box
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dec.copy_(d_in)
+        e0.record()
+        for _ in range(5):
+            dec.copy_(d_in)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         res = {
             "metric": "encode+decode GB/s (input bytes)", "value": round(value, 3), "unit": "GB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -273,7 +283,10 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": cand[dom][0], "avg_launch_ms": round(cand[dom][1], 4)},
+                         "algorithmic_bytes_per_launch": cand[dom][0], "avg_launch_ms": round(cand[dom][1], 4),
+                         "copy_probe_GBps": round(copy_gbps, 1),
+                         "all_kernels": {k: {"achieved": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                                         for k, v in cand.items() if v[1] > 0}},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(d_in.cpu().numpy(), args.kind)

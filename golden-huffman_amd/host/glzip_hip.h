@@ -121,6 +121,57 @@ inline size_t file_size(FILE* f) {
   return n < 0 ? 0 : (size_t)n;
 }
 
+// What replaces the reference's 64 KiB FixedFileBuffer (utils/include/buffer.h:61-317): files move between disk
+// and HBM in 32 MiB pieces through TWO pinned buffers, each with its own copy stream, so the fread/fwrite of one
+// piece overlaps the hipMemcpyAsync of the other.
+class Stager {
+ public:
+  static const size_t kPiece = 32u << 20;
+  Stager() {}
+  // file -> device, n bytes from the current file position
+  void to_device(FILE* f, uint8_t* d_dst, size_t n, const std::string& what) {
+    ensure();
+    size_t off = 0;
+    for (int k = 0; off < n; ++k) {
+      const int b = k & 1;
+      const size_t len = n - off < kPiece ? n - off : kPiece;
+      s_[b].sync("stager");  // the copy that last used this buffer is done
+      if (fread(h_[b].p, 1, len, f) != len) throw Error(GHF_E_INVAL, "short read on " + what);
+      s_[b].check(ghf_copy_h2d(s_[b].ctx(), d_dst + off, h_[b].p, len), "ghf_copy_h2d");
+      off += len;
+    }
+    s_[0].sync("stager");
+    s_[1].sync("stager");
+  }
+  // device -> file, n bytes appended at the current file position
+  void to_file(const uint8_t* d_src, size_t n, FILE* f, const std::string& what) {
+    ensure();
+    size_t off = 0, pending_len[2] = {0, 0};
+    for (int k = 0; off < n || pending_len[k & 1] || pending_len[(k + 1) & 1]; ++k) {
+      const int b = k & 1;
+      if (pending_len[b]) {  // the copy issued two rounds ago into this buffer: wait, then write it out
+        s_[b].sync("stager");
+        if (fwrite(h_[b].p, 1, pending_len[b], f) != pending_len[b]) throw Error(GHF_E_INVAL, "short write on " + what);
+        pending_len[b] = 0;
+      }
+      if (off < n) {
+        const size_t len = n - off < kPiece ? n - off : kPiece;
+        s_[b].check(ghf_copy_d2h(s_[b].ctx(), h_[b].p, d_src + off, len), "ghf_copy_d2h");
+        pending_len[b] = len;
+        off += len;
+      }
+    }
+  }
+
+ private:
+  void ensure() {
+    for (int b = 0; b < 2; ++b)
+      if (!h_[b].p) h_[b].alloc(s_[b], kPiece);
+  }
+  Session s_[2];
+  PinnedBuf h_[2];
+};
+
 }  // namespace detail
 
 // ------------------------------------------------------------------------------------------------ Compressor
@@ -192,11 +243,9 @@ class HipCanonicalHuffEncoder<unsigned char> {
   void caculate_frequency() {
     n_ = detail::file_size(infile_);
     if (n_ == 0) throw Error(GHF_E_EMPTY, "empty input: undefined in the reference, refused here");
-    h_in_.alloc(s_, n_);
-    if (fread(h_in_.p, 1, n_, infile_) != n_) throw Error(GHF_E_INVAL, "short read on " + infile_name_);
     d_in_.alloc(s_, n_ + 16);
     d_hist_.alloc(s_, GHF_NSYM * sizeof(uint64_t));
-    s_.check(ghf_copy_h2d(s_.ctx(), d_in_.p, h_in_.p, n_), "ghf_copy_h2d");
+    stager_.to_device(infile_, d_in_.u8(), n_, infile_name_);  // pieces: fread overlaps hipMemcpyAsync
     s_.check(ghf_histogram(s_.ctx(), d_in_.u8(), n_, static_cast<uint64_t*>(d_hist_.p)), "ghf_histogram");
   }
 
@@ -213,7 +262,7 @@ class HipCanonicalHuffEncoder<unsigned char> {
     const size_t hdr = ghf_header_bytes(code_.max_len);
     cap_ = ghf_compress_bound(n_);
     d_out_.alloc(s_, cap_);
-    h_out_.alloc(s_, cap_);
+    h_out_.alloc(s_, 2048);  // the header only (<= 1296 bytes); the body is streamed through the stager
     s_.check(ghf_write_header(s_.ctx(), static_cast<const ghf_code*>(d_code_.p), d_out_.u8(), cap_), "ghf_write_header");
     s_.check(ghf_copy_d2h(s_.ctx(), h_out_.p, d_out_.p, hdr), "ghf_copy_d2h");
     s_.sync("write_encode_info");
@@ -236,9 +285,7 @@ class HipCanonicalHuffEncoder<unsigned char> {
     s_.check(ghf_copy_d2h(s_.ctx(), end, d_end.p, sizeof end), "ghf_copy_d2h");
     s_.sync("encode_file");
     const size_t total = (size_t)end[1];
-    s_.check(ghf_copy_d2h(s_.ctx(), h_out_.u8() + hdr, d_out_.u8() + hdr, total - hdr), "ghf_copy_d2h");
-    s_.sync("encode_file");
-    if (fwrite(h_out_.u8() + hdr, 1, total - hdr, outfile_) != total - hdr) throw Error(GHF_E_INVAL, "short write (body)");
+    stager_.to_file(d_out_.u8() + hdr, total - hdr, outfile_, "output (body)");  // pieces: fwrite overlaps the D2H copies
     fflush(outfile_);
   }
 
@@ -252,8 +299,9 @@ class HipCanonicalHuffEncoder<unsigned char> {
   FILE* outfile_;
   std::string infile_name_;
   size_t n_, cap_;
-  detail::PinnedBuf h_in_, h_out_;
+  detail::PinnedBuf h_out_;
   detail::DeviceBuf d_in_, d_hist_, d_code_, d_out_;
+  detail::Stager stager_;
   ghf_code code_;
 };
 
@@ -283,26 +331,25 @@ class HipCanonicalHuffDecoder<unsigned char> {
   // include/canonical_huff_encoder.cc:349-374 -- plus the validation the reference does not do
   void get_encode_info() {
     n_ = detail::file_size(infile_);
-    h_in_.alloc(s_, n_ + 16);
-    if (fread(h_in_.p, 1, n_, infile_) != n_) throw Error(GHF_E_INVAL, "short read");
-    s_.check(ghf_parse_header(h_in_.u8(), n_, &code_, &hdr_), "ghf_parse_header");
+    std::vector<uint8_t> head(n_ < 1296 ? n_ : 1296);  // the largest header: 1040 + 8 * 32
+    if (fread(head.data(), 1, head.size(), infile_) != head.size()) throw Error(GHF_E_INVAL, "short read");
+    s_.check(ghf_parse_header(head.data(), head.size(), &code_, &hdr_), "ghf_parse_header");
+    fseek(infile_, 0, SEEK_SET);
   }
 
   // include/canonical_huff_encoder.cc:377-419 (and :422-461, :519-568): runs until the end mark
   void decode_file() {
     d_in_.alloc(s_, n_ + 16);
     d_code_.alloc(s_, sizeof(ghf_code));
-    s_.check(ghf_copy_h2d(s_.ctx(), d_in_.p, h_in_.p, n_), "ghf_copy_h2d");
+    stager_.to_device(infile_, d_in_.u8(), n_, "input");
     s_.check(ghf_copy_h2d(s_.ctx(), d_code_.p, &code_, sizeof(ghf_code)), "ghf_copy_h2d");
     const ghf_code* dc = static_cast<const ghf_code*>(d_code_.p);
     uint64_t n_out = 0;
     s_.check(ghf_decoded_size(s_.ctx(), d_in_.u8(), n_, dc, &n_out), "ghf_decoded_size");
     d_out_.alloc(s_, (size_t)n_out + 16);
-    h_out_.alloc(s_, (size_t)n_out + 16);
     s_.check(ghf_decode(s_.ctx(), d_in_.u8(), n_, dc, NULL, d_out_.u8(), (size_t)n_out + 16, NULL), "ghf_decode");
-    s_.check(ghf_copy_d2h(s_.ctx(), h_out_.p, d_out_.p, (size_t)n_out), "ghf_copy_d2h");
     s_.sync("decode_file");
-    if (fwrite(h_out_.p, 1, (size_t)n_out, outfile_) != (size_t)n_out) throw Error(GHF_E_INVAL, "short write");
+    stager_.to_file(d_out_.u8(), (size_t)n_out, outfile_, "output");
     fflush(outfile_);
   }
 
@@ -313,8 +360,8 @@ class HipCanonicalHuffDecoder<unsigned char> {
   FILE* infile_;
   FILE* outfile_;
   size_t n_, hdr_;
-  detail::PinnedBuf h_in_, h_out_;
   detail::DeviceBuf d_in_, d_code_, d_out_;
+  detail::Stager stager_;
   ghf_code code_;
 };
 

@@ -73,3 +73,18 @@ def test_errors_are_reported_not_undefined(tool, tmp_path):
     junk.write_bytes(bytes(range(256)) * 8)
     assert subprocess.run([tool, str(junk), "4"], capture_output=True, timeout=60).returncode == 1
     assert subprocess.run([tool, str(tmp_path / "missing.bin"), "3"], capture_output=True, timeout=60).returncode == 1
+
+
+def test_streaming_stager_multi_piece_file(tool, tmp_path):
+    """a 70 MiB file = three 32 MiB staging pieces each way (double-buffered pinned buffers, two copy streams)"""
+    import datagen as dg
+
+    data = dg.zipf_bytes((70 << 20) + 12345, seed=77)
+    f = tmp_path / "big.bin"
+    data.tofile(f)
+    assert subprocess.run([tool, str(f), "3"], timeout=300).returncode == 0
+    crs = np.fromfile(str(f) + ".crs2", dtype=np.uint8)
+    ref = orc.compress(data)
+    assert crs.size == ref.size and sha(crs) == sha(ref)
+    assert subprocess.run([tool, str(f) + ".crs2", "6"], timeout=300).returncode == 0
+    assert np.array_equal(np.fromfile(str(f) + ".crs2.de", dtype=np.uint8), data)
