@@ -29,6 +29,7 @@ constexpr int kStageCapBits = (kStageWords - 8) * 32;
 // K7 decode
 constexpr int kDecThreads = 256;
 constexpr int kDecWaves = kDecThreads / kWave;
+constexpr int kDecPairBitsMax = 10;
 constexpr int kDecLutBitsMax = 12;
 constexpr int kDecInBytes = 5120;                 // staged compressed span per wave (4096 symbols at <= 10 bits average)
 constexpr int kDecInWords = kDecInBytes / 4;
@@ -45,12 +46,15 @@ struct DecTables {
   uint32_t start_pos[36];
   uint16_t symbol[GHF_NSYM + 3];
   int32_t min_len, max_len, lut_bits;
-  uint32_t pad_;
+  int32_t pair_bits;       // 2 * max_len when that is <= kDecPairBitsMax (every pair of codes fits lut2's index), else 0
   // work counters of k_decode, zeroed by k_build_decode_tables.  One word saturates at ~88 tickets/us (measured:
   // a single counter made the 256 MiB decode 4.8x slower), so the workgroups are split into 16 classes
   // (blockIdx % 16), each with its own counter on its own 128-byte line; class c owns the groups == c (mod 16).
   uint32_t ticket[16 * 32];
   uint16_t lut[1 << kDecLutBitsMax];  // sym | len << 9 ; 0 = code longer than lut_bits
+  // two symbols per lookup for small alphabets (max_len <= 5): index = next pair_bits stream bits,
+  // entry = sym0 | sym1 << 8 | (len0 + len1) << 16 ; bit 30 = not two data symbols (end mark / no such code)
+  uint32_t lut2[1 << kDecPairBitsMax];
 };
 
 struct EmitParams {

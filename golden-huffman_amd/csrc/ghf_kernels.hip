@@ -1093,6 +1093,31 @@ __global__ __launch_bounds__(256) void k_build_decode_tables(const ghf_code* __r
     }
     dt->lut[idx] = ent;
   }
+  // two symbols per lookup when any two codes fit the index (small alphabets: 16-symbol data has max_len 5)
+  const int pb = 2 * max_len <= kDecPairBitsMax ? 2 * max_len : 0;
+  if (tid == 0) dt->pair_bits = pb;
+  auto one = [&](uint32_t v) -> uint32_t {  // sym | len << 9 of the code at the top of v; 0: none
+    for (int len = min_len; len <= max_len; ++len) {
+      if (v >= fcl[len]) {
+        const uint32_t k = sp[len] + ((v - fcl[len]) >> (32 - len));
+        const uint32_t sym = k < GHF_NSYM ? code->symbol[k] : 256u;
+        return (sym > 256u ? 256u : sym) | ((uint32_t)len << 9);
+      }
+    }
+    return 0u;
+  };
+  for (uint32_t idx = tid; pb && idx < (1u << pb); idx += 256) {
+    const uint32_t v = idx << (32 - pb);
+    const uint32_t e0 = one(v);
+    uint32_t ent = (1u << 30) | (1u << 16);  // not a data symbol: flagged, one bit consumed
+    if (e0 && (e0 & 0x1FFu) != 256u) {
+      const uint32_t l0 = e0 >> 9;
+      const uint32_t e1 = one(v << l0);
+      if (e1 && (e1 & 0x1FFu) != 256u) ent = (e0 & 0xFFu) | ((e1 & 0xFFu) << 8) | ((l0 + (e1 >> 9)) << 16);
+      else ent = (1u << 30) | (l0 << 16);
+    }
+    dt->lut2[idx] = ent;
+  }
 }
 
 void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_status, hipStream_t s) {
@@ -1115,15 +1140,19 @@ struct DecLds {  // K6 (side-car reconstruction): 4 waves, plain table
 // 12-bit tables -> 4 copies (skewed data hits few, mostly identical entries anyway: identical addresses broadcast).
 constexpr int kDec7Threads = 512;
 constexpr int kDec7Waves = kDec7Threads / kWave;
-constexpr int kDec7LutLog2 = 14;
+constexpr int kDec7LutLog2 = 12;
+constexpr int kDec7InBytes = 4608;  // staged span per wave: 4096 symbols at <= 9 bits average (a byte-Huffman code averages <= 8.1)
+constexpr int kDec7InWords = kDec7InBytes / 4;
 struct DecLds7 {
-  alignas(16) uint32_t in[kDec7Waves][kDecInWords + 4];
+  alignas(16) uint32_t in[kDec7Waves][kDec7InWords + 4];  // compressed span of the wave's group, big-endian words
+  alignas(16) uint32_t out[kDec7Waves][1024];             // the group's 4096 output bytes, lane-major, before the copy-out
   alignas(16) uint16_t lut[1 << kDec7LutLog2];
   uint32_t fcl[36];
   uint32_t sp[36];
   uint16_t symbol[GHF_NSYM + 3];
   int status0;
 };
+static_assert(sizeof(DecLds7) <= 80 * 1024, "two workgroups per CU");
 
 template <typename LT>
 __device__ __forceinline__ void dec_small_load(LT& L, const DecTables* dt, int tid, int nthreads) {
@@ -1142,13 +1171,22 @@ __device__ __forceinline__ void dec_lds_load(DecLds& L, const DecTables* dt, int
   dec_small_load(L, dt, tid, nthreads);
 }
 
-// replicated fill: entry idx, copy r at lut[(idx << rshift) | r]
+// replicated fill: entry idx, copy r at lut[(idx << rshift) | r].  With a pair table the 32 KiB are split:
+// lower half = lut2 (4096 u32 slots), upper half = the one-symbol table (8192 u16 slots, used for ragged tails
+// and the end mark).
 __device__ __forceinline__ void dec_lds_load7(DecLds7& L, const DecTables* dt, int tid, int nthreads) {
-  const int rshift = kDec7LutLog2 - dt->lut_bits;
-  uint32_t* dst = reinterpret_cast<uint32_t*>(L.lut);
-  for (int i = tid; i < (1 << (kDec7LutLog2 - 1)); i += nthreads) {  // two u16 slots per store
+  const int pb = dt->pair_bits;
+  const int slots_log2 = pb ? kDec7LutLog2 - 1 : kDec7LutLog2;
+  const int rshift = slots_log2 - dt->lut_bits;
+  uint32_t* dst = reinterpret_cast<uint32_t*>(L.lut + (pb ? (1 << (kDec7LutLog2 - 1)) : 0));
+  for (int i = tid; i < (1 << (slots_log2 - 1)); i += nthreads) {  // two u16 slots per store
     const uint32_t a = dt->lut[(2 * i) >> rshift], b = dt->lut[(2 * i + 1) >> rshift];
     dst[i] = a | (b << 16);
+  }
+  if (pb) {
+    uint32_t* d2 = reinterpret_cast<uint32_t*>(L.lut);
+    const int r2 = kDecPairBitsMax - pb;
+    for (int i = tid; i < (1 << kDecPairBitsMax); i += nthreads) d2[i] = dt->lut2[i >> r2];
   }
   dec_small_load(L, dt, tid, nthreads);
 }
@@ -1187,10 +1225,14 @@ struct DecIn {
 #else
 #define GHF_EXP_LUT(real, v) (real)
 #endif
-template <bool STAGED, int K, bool LONG, typename LT>
+// LDSOUT: the 16-byte pieces go to the wave's LDS tile (`outl` = this lane's 64-byte row, pieces XOR-swizzled by
+// `osw` so that the 16 lanes of a write phase hit 16 different bank groups); the caller copies the tile out.
+template <bool STAGED, int K, bool LONG, bool PAIR, bool LDSOUT, typename LT>
 __device__ __forceinline__ uint32_t decode_segment(const LT& L, const DecIn<STAGED>& I, int lut_bits, int max_len,
                                                    uint64_t pos, uint32_t cnt, bool valid, bool all_full, uint8_t* optr,
-                                                   int has_next, uint64_t expect_bits, int rshift, uint32_t rep) {
+                                                   int has_next, uint64_t expect_bits, int rshift, uint32_t rep,
+                                                   const uint16_t* lut1, int pair_bits, uint32_t rep2, uint32_t* outl,
+                                                   uint32_t osw) {
   const int lsh = 32 - lut_bits;
   uint32_t widx = (uint32_t)(pos >> 5);
   uint32_t o = (uint32_t)(pos & 31u);
@@ -1218,7 +1260,7 @@ __device__ __forceinline__ uint32_t decode_segment(const LT& L, const DecIn<STAG
 #define GHF_DEC(ENT)                                          \
   do {                                                        \
     const uint32_t v_ = (uint32_t)((W << o) >> 32);           \
-    ENT = GHF_EXP_LUT(L.lut[((v_ >> lsh) << rshift) | rep], v_); \
+    ENT = GHF_EXP_LUT(lut1[((v_ >> lsh) << rshift) | rep], v_); \
     if (LONG && __builtin_expect((ENT >> 9) == 0, 0)) {       \
       const uint32_t r_ = dec_long(L, v_, lut_bits, max_len); \
       ENT = (r_ & 0x1FFu) | ((r_ >> 16) << 9);                \
@@ -1226,13 +1268,48 @@ __device__ __forceinline__ uint32_t decode_segment(const LT& L, const DecIn<STAG
     o += ENT >> 9;                                            \
   } while (0)
 
-  if (STAGED && all_full) {
+  if (STAGED && PAIR && all_full) {
+    // small alphabet: any two codes fit lut2's index, so one lookup yields two symbols and the serial
+    // shift -> lookup -> add chain is half as long.  Two pairs (<= 2 * pair_bits <= 24 bits) per refill check.
+    const uint32_t* lut2 = reinterpret_cast<const uint32_t*>(L.lut);
+    const int psh = 32 - pair_bits, r2 = kDecPairBitsMax - pair_bits;
+    uint32_t bad2 = 0;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      uint32_t wq[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#if defined(GHF_EXP) && (GHF_EXP == 8 || GHF_EXP == 9)
+        wq[k] = W + k + q; continue;
+#endif
+        GHF_REFILL();
+        const uint32_t va = (uint32_t)((W << o) >> 32);
+        const uint32_t ea = lut2[((va >> psh) << r2) | rep2];
+        o += (ea >> 16) & 31u;
+        const uint32_t vb = (uint32_t)((W << o) >> 32);
+        const uint32_t eb = lut2[((vb >> psh) << r2) | rep2];
+        o += (eb >> 16) & 31u;
+        bad2 |= ea | eb;
+        wq[k] = __builtin_amdgcn_perm(eb, ea, 0x05040100u);  // {ea.sym0, ea.sym1, eb.sym0, eb.sym1}
+      }
+#if defined(GHF_EXP) && (GHF_EXP == 2 || GHF_EXP == 9)
+      if (valid && wq[0] == 0x12345678u && wq[1] == 0x9abcdef0u) store16_untracked(optr + q * 16, wq[0], wq[1], wq[2], wq[3]);
+#else
+      if (LDSOUT) *reinterpret_cast<uint4*>(outl + (((uint32_t)q ^ osw) << 2)) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+      else if (valid) *reinterpret_cast<uint4*>(optr + q * 16) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+#endif
+    }
+    bad_acc |= (bad2 >> 22) & 256u;
+  } else if (STAGED && all_full) {
     // full segments everywhere (all groups but the stream's last): 16 output bytes per store
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
       uint32_t wq[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+#if defined(GHF_EXP) && (GHF_EXP == 8 || GHF_EXP == 9)
+        wq[k] = W + k + q; continue;
+#endif
         uint32_t e[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -1245,10 +1322,11 @@ __device__ __forceinline__ uint32_t decode_segment(const LT& L, const DecIn<STAG
         const uint32_t hi = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0400u);
         wq[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
       }
-#if defined(GHF_EXP) && GHF_EXP == 2
-      if (valid && wq[0] == 0x12345678u && wq[1] == 0x9abcdef0u) *reinterpret_cast<uint4*>(optr + q * 16) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+#if defined(GHF_EXP) && (GHF_EXP == 2 || GHF_EXP == 9)
+      if (valid && wq[0] == 0x12345678u && wq[1] == 0x9abcdef0u) store16_untracked(optr + q * 16, wq[0], wq[1], wq[2], wq[3]);
 #else
-      if (valid) *reinterpret_cast<uint4*>(optr + q * 16) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+      if (LDSOUT) *reinterpret_cast<uint4*>(outl + (((uint32_t)q ^ osw) << 2)) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+      else if (valid) *reinterpret_cast<uint4*>(optr + q * 16) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
 #endif
     }
   } else if (valid) {
@@ -1290,13 +1368,30 @@ struct DecGroup {      // what a lane knows about its segment in one group (all 
   uint64_t span;       // uniform: staged bytes
 };
 
-__device__ __forceinline__ void dec_load_meta(const DecParams& P, uint64_t group, int lane, uint64_t& sbit, uint64_t& nbit) {
+// Side-car words of a lane's segment and of the one after it, as loaded: the loads are issued a whole pass before
+// dec_meta_bits() combines them, and nothing in between may need their values (a single dependent use right behind
+// the loads makes the compiler wait for every older memory operation, including the span prefetch).
+struct DecMeta {
+  uint64_t cb0, cb1;
+  uint32_t sb0, sb1;
+};
+
+__device__ __forceinline__ void dec_issue_meta(const DecParams& P, uint64_t group, int lane, DecMeta& M) {
+  const uint64_t last = P.n_segs - 1;
+  const uint64_t seg = group * 64 + lane;
+  const uint64_t s0 = seg < last ? seg : last, s1 = seg + 1 < last ? seg + 1 : last;  // clamped: unconditional loads
+  M.cb0 = P.chunk_bit[(s0 * kSegSymbols) >> P.chunk_log2];
+  M.sb0 = P.seg_bit[s0];
+  M.cb1 = P.chunk_bit[(s1 * kSegSymbols) >> P.chunk_log2];
+  M.sb1 = P.seg_bit[s1];
+}
+
+__device__ __forceinline__ void dec_meta_bits(const DecParams& P, uint64_t group, int lane, const DecMeta& M, uint64_t& sbit,
+                                              uint64_t& nbit) {
   const uint64_t stream_end_bit = P.stream_bytes * 8;
   const uint64_t seg = group * 64 + lane;
-  sbit = stream_end_bit;
-  nbit = stream_end_bit;
-  if (seg < P.n_segs) sbit = P.chunk_bit[(seg * kSegSymbols) >> P.chunk_log2] + P.seg_bit[seg];
-  if (seg + 1 < P.n_segs) nbit = P.chunk_bit[((seg + 1) * kSegSymbols) >> P.chunk_log2] + P.seg_bit[seg + 1];
+  sbit = seg < P.n_segs ? M.cb0 + M.sb0 : stream_end_bit;
+  nbit = seg + 1 < P.n_segs ? M.cb1 + M.sb1 : stream_end_bit;
 }
 
 __device__ __forceinline__ void dec_span(const DecParams& P, uint64_t group, int lane, int max_len, DecGroup& G) {
@@ -1322,9 +1417,9 @@ __device__ __forceinline__ void dec_span(const DecParams& P, uint64_t group, int
   G.span = byte1 - G.byte0;
 }
 
-constexpr int kDecVec = kDecInBytes / 1024;  // 16-byte vectors per lane that cover a staged span
+constexpr int kDecVec = (kDec7InBytes + 1023) / 1024;  // 16-byte vectors per lane that cover a staged span
 
-__global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
+__global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
   __shared__ DecLds7 L;
   const int tid = threadIdx.x;
   if (tid == 0) L.status0 = *P.status;  // one read per workgroup: the exit must be uniform
@@ -1333,8 +1428,11 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
   const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
   dec_lds_load7(L, P.dt, tid, kDec7Threads);
   __syncthreads();
-  const int rshift = kDec7LutLog2 - lut_bits;
+  const int pair_bits = P.dt->pair_bits;
+  const int rshift = (pair_bits ? kDec7LutLog2 - 1 : kDec7LutLog2) - lut_bits;
   const uint32_t rep = (uint32_t)tid & ((1u << rshift) - 1u);
+  const uint32_t rep2 = (uint32_t)tid & ((1u << (kDecPairBitsMax - pair_bits)) - 1u);
+  const uint16_t* lut1 = L.lut + (pair_bits ? (1 << (kDec7LutLog2 - 1)) : 0);
   if (blockIdx.x == 0 && tid == 0 && P.out_bytes) *P.out_bytes = P.n_symbols;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar loop control
@@ -1348,14 +1446,17 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
   // another kernel occupied its CU) simply takes fewer groups instead of becoming the kernel's straggler
   const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;  // every class needs at least one workgroup
   const uint32_t cls = blockIdx.x % ncls;
-  auto ticket = [&]() -> uint64_t {
+  auto ticket_issue = [&]() -> unsigned int {  // the atomic's return value stays in a VGPR until ticket_group() needs it
     unsigned int t = 0;
     if (lane == 0) t = atomicAdd(&P.dt->ticket[cls * 32], 1u);
+    return t;
+  };
+  auto ticket_group = [&](unsigned int t) -> uint64_t {
     return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * ncls + cls;
   };
-  uint64_t group = ticket();
+  uint64_t group = ticket_group(ticket_issue());
   if (group >= ngroups) return;
-  uint64_t g1 = ticket(), g2 = ticket();  // the next two groups of this wave (their loads are issued ahead)
+  uint64_t g1 = ticket_group(ticket_issue()), g2 = ticket_group(ticket_issue());  // this wave's next two groups
   const uint64_t glast = ngroups - 1;
   auto clampg = [&](uint64_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
 
@@ -1371,13 +1472,19 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
 
   DecGroup cur, nxt;
   uint4 R[kDecVec];
-  uint64_t sbit2, nbit2;  // side-car entries of the group after next
-  dec_load_meta(P, group, lane, cur.sbit, cur.nbit);
+  DecMeta M;  // raw side-car words of the group after `cur` (of the one after that once the pass has issued its loads)
+  dec_issue_meta(P, group, lane, M);
+  dec_meta_bits(P, group, lane, M, cur.sbit, cur.nbit);
   dec_span(P, group, lane, max_len, cur);
   issue(cur, R);
-  dec_load_meta(P, clampg(g1), lane, nxt.sbit, nxt.nbit);
+  dec_issue_meta(P, clampg(g1), lane, M);
 
-  for (; group < ngroups;) {
+  // One pass over a group.  HOT = the group is complete, staged, plausible and not the stream's last: the body then has
+  // no data-dependent branch around its memory operations, so the compiler can count them -- the wait for the
+  // prefetched span becomes "all but the youngest four" (this group's output stores) instead of vmcnt(0), and the wave
+  // no longer sleeps until its own stores are acknowledged by L2 (which is what bounded this kernel before).
+  auto pass = [&](auto hot_tag) {
+    constexpr bool HOT = decltype(hot_tag)::value;
     // ---- 1. this group's span: registers -> LDS (big-endian words); everything behind it reads as zero
     wave_sync();
 #pragma unroll
@@ -1386,64 +1493,110 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
       const bool ok = (o < cur.span) && (cur.byte0 + o + 16 <= full_bytes);
       uint4 v = R[k];
       v = ok ? make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)) : make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(in + (o >> 2)) = v;
+      if ((k + 1) * 1024 <= kDec7InBytes || o < (uint64_t)kDec7InBytes) *reinterpret_cast<uint4*>(in + (o >> 2)) = v;
     }
-    if (lane < 4) in[kDecInWords + lane] = 0;
-    if (cur.byte0 + cur.span > full_bytes && full_bytes >= cur.byte0 && lane == 0) {
+    if (lane < 4) in[kDec7InWords + lane] = 0;
+    if (!HOT && cur.byte0 + cur.span > full_bytes && full_bytes >= cur.byte0 && lane == 0) {
       // the stream's last, incomplete 16 bytes: byte loads, never past the end of the buffer
       uint32_t q[4] = {0, 0, 0, 0};
       for (uint64_t j = 0; full_bytes + j < P.stream_bytes; ++j) q[j >> 2] |= (uint32_t)P.stream[full_bytes + j] << (24 - 8 * (j & 3));
       const uint64_t w = (full_bytes - cur.byte0) >> 2;
-      if (w + 3 < (uint64_t)kDecInWords + 4) {
+      if (w + 3 < (uint64_t)kDec7InWords + 4) {
         in[w] = q[0]; in[w + 1] = q[1]; in[w + 2] = q[2]; in[w + 3] = q[3];
       }
     }
     wave_sync();
     // ---- prefetch: span of the next group (its side-car entries arrived during the last decode), side-car of the one after
+    dec_meta_bits(P, clampg(g1), lane, M, nxt.sbit, nxt.nbit);  // loaded a pass ago
     dec_span(P, clampg(g1), lane, max_len, nxt);
     issue(nxt, R);
-    dec_load_meta(P, clampg(g2), lane, sbit2, nbit2);
-    const uint64_t g3 = ticket();  // returns long before it is needed
+    dec_issue_meta(P, clampg(g2), lane, M);
+    const unsigned int t3 = ticket_issue();  // resolved after the decode
     // ---- 2./3. decode
     const uint64_t seg0 = group * 64;
     const uint64_t seg = seg0 + lane;
-    const bool valid = seg < P.n_segs;
-    const bool bad = valid && (cur.sbit >= stream_end_bit || cur.nbit > stream_end_bit || cur.nbit < cur.sbit ||
-                               cur.sbit < cur.byte0 * 8);
-    if (__ballot(bad)) {
-      if (bad) latch_status(P.status, GHF_E_CORRUPT);
+    const uint64_t sym0 = seg * kSegSymbols;
+    const uint64_t pos = cur.sbit - cur.byte0 * 8;
+    uint8_t* optr = P.out + sym0;
+    const uint64_t expect = cur.nbit - cur.sbit;
+    const uint8_t* src = P.stream + cur.byte0;
+    uint32_t* outl = L.out[wave] + lane * 16;
+    const uint32_t osw = ((uint32_t)lane >> 2) & 3u;
+#define GHF_SEG_ARGS L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep, lut1, pair_bits, rep2, outl, osw
+    if (HOT) {
+      const uint32_t cnt = kSegSymbols;
+      const bool valid = true, all_full = true;
+      const int has_next = 1;
+      DecIn<true> I{in, src, cur.span};
+      // K = 32 / max_len symbols per refill check; LONG = codes beyond the direct table exist
+      if (pair_bits) bad_acc |= decode_segment<true, 4, false, true, true>(GHF_SEG_ARGS);
+      else if (max_len <= 8) bad_acc |= decode_segment<true, 4, false, false, true>(GHF_SEG_ARGS);
+      else if (max_len <= 10) bad_acc |= decode_segment<true, 3, false, false, true>(GHF_SEG_ARGS);
+      else if (max_len <= kDecLutBitsMax) bad_acc |= decode_segment<true, 2, false, false, true>(GHF_SEG_ARGS);
+      else if (max_len <= 16) bad_acc |= decode_segment<true, 2, true, false, true>(GHF_SEG_ARGS);
+      else bad_acc |= decode_segment<true, 1, true, false, true>(GHF_SEG_ARGS);
+      // copy-out: four fully coalesced 1 KiB stores per wave, straight-line, so that the compiler can count them and
+      // the next pass waits for "all but the youngest four" memory operations instead of for everything (the stores
+      // used to sit in the rolled decode loop: every pass slept until L2 had acknowledged its own stores, and 16-byte
+      // pieces at a 64-byte stride reached HBM as 1.31x the output bytes)
+      wave_sync();
+      {
+        const uint32_t* ot = L.out[wave];
+        uint8_t* og = P.out + seg0 * kSegSymbols + (uint32_t)lane * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t sl = (uint32_t)r * 16 + ((uint32_t)lane >> 2);        // the lane whose row holds my piece
+          const uint32_t piece = ((uint32_t)lane & 3u) ^ ((sl >> 2) & 3u);
+          const uint4 v = *reinterpret_cast<const uint4*>(ot + sl * 16 + piece * 4);
+          *reinterpret_cast<uint4*>(og + r * 1024) = v;
+        }
+      }
     } else {
-      const bool staged = cur.span <= (uint64_t)kDecInBytes;
-      const uint64_t sym0 = seg * kSegSymbols;
-      uint32_t cnt = 0;
-      if (valid) cnt = (P.n_symbols - sym0 >= (uint64_t)kSegSymbols) ? (uint32_t)kSegSymbols : (uint32_t)(P.n_symbols - sym0);
-      const uint64_t pos = cur.sbit - cur.byte0 * 8;
-      const bool all_full = (__ballot(valid && cnt != (uint32_t)kSegSymbols) == 0) && out_aligned;
-      // 1: the side-car says where the next segment starts; 0: the end mark must follow; 2: nothing to check
-      const int has_next = seg + 1 < P.n_segs ? 1 : (P.no_end_mark ? 2 : 0);
-      uint8_t* optr = P.out + sym0;
-      const uint64_t expect = cur.nbit - cur.sbit;
-      const uint8_t* src = P.stream + cur.byte0;
-      if (staged) {
-        DecIn<true> I{in, src, cur.span};
-        // K = 32 / max_len symbols per refill check; LONG = codes beyond the direct table exist
-        if (max_len <= 8) bad_acc |= decode_segment<true, 4, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
-        else if (max_len <= 10) bad_acc |= decode_segment<true, 3, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
-        else if (max_len <= kDecLutBitsMax) bad_acc |= decode_segment<true, 2, false>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
-        else if (max_len <= 16) bad_acc |= decode_segment<true, 2, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
-        else bad_acc |= decode_segment<true, 1, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
+      const bool valid = seg < P.n_segs;
+      const bool bad = valid && (cur.sbit >= stream_end_bit || cur.nbit > stream_end_bit || cur.nbit < cur.sbit ||
+                                 cur.sbit < cur.byte0 * 8);
+      if (__ballot(bad)) {
+        if (bad) latch_status(P.status, GHF_E_CORRUPT);
       } else {
-        DecIn<false> I{in, src, cur.span};
-        bad_acc |= decode_segment<false, 1, true>(L, I, lut_bits, max_len, pos, cnt, valid, all_full, optr, has_next, expect, rshift, rep);
+        const bool staged = cur.span <= (uint64_t)kDec7InBytes;
+        uint32_t cnt = 0;
+        if (valid) cnt = (P.n_symbols - sym0 >= (uint64_t)kSegSymbols) ? (uint32_t)kSegSymbols : (uint32_t)(P.n_symbols - sym0);
+        const bool all_full = (__ballot(valid && cnt != (uint32_t)kSegSymbols) == 0) && out_aligned;
+        // 1: the side-car says where the next segment starts; 0: the end mark must follow; 2: nothing to check
+        const int has_next = seg + 1 < P.n_segs ? 1 : (P.no_end_mark ? 2 : 0);
+        if (staged) {
+          DecIn<true> I{in, src, cur.span};
+          if (max_len <= 8) bad_acc |= decode_segment<true, 4, false, false, false>(GHF_SEG_ARGS);
+          else if (max_len <= kDecLutBitsMax) bad_acc |= decode_segment<true, 2, false, false, false>(GHF_SEG_ARGS);
+          else bad_acc |= decode_segment<true, 1, true, false, false>(GHF_SEG_ARGS);
+        } else {
+          DecIn<false> I{in, src, cur.span};
+          bad_acc |= decode_segment<false, 1, true, false, false>(GHF_SEG_ARGS);
+        }
       }
     }
+#undef GHF_SEG_ARGS
     // ---- rotate (all of these values have long arrived)
     cur = nxt;
-    nxt.sbit = sbit2;
-    nxt.nbit = nbit2;
     group = g1;
     g1 = g2;
-    g2 = g3;
+    g2 = ticket_group(t3);
+  };
+  auto is_hot = [&]() -> bool {  // wave-uniform
+    if (group + 1 >= ngroups || !out_aligned) return false;                   // the last group may be ragged / carries the end mark
+    if (cur.span > (uint64_t)kDec7InBytes || cur.byte0 + cur.span > full_bytes) return false;
+    const bool bad = cur.sbit >= stream_end_bit || cur.nbit > stream_end_bit || cur.nbit < cur.sbit || cur.sbit < cur.byte0 * 8;
+    return __ballot(bad) == 0;
+  };
+  while (group < ngroups) {
+    if (is_hot()) {
+      // drain once on entry: the hot loop's waits are then computed from its own back edge alone (exact counts)
+      // instead of being merged with whatever the cold paths left outstanding
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      do pass(std::true_type{});
+      while (is_hot());
+    }
+    if (group < ngroups) pass(std::false_type{});
   }
 #ifndef GHF_EXP
   if (bad_acc & 256u) latch_status(P.status, GHF_E_CORRUPT);  // a data symbol can never be 256

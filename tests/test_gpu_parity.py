@@ -286,3 +286,47 @@ def test_random_sweep_sizes_and_alphabets(env):
                 out2, n2 = ctx.decode(d_out, nb, d_code, None, cap=n + 64)
                 ctx.sync()
                 assert int(n2.item()) == n and np.array_equal(out2[:n].cpu().numpy(), data), (kind, mod, n, "foreign")
+
+
+def test_small_alphabets_two_symbols_per_lookup(env):
+    """max_len <= 6 switches K7 to its pair table (two symbols per lookup).  Alphabets of 1..48 symbols, flat and
+    skewed, sizes that end exactly on / just off a 4096-symbol group, decode with and without the side-car, and a
+    flipped body bit must still be reported."""
+    ghf, ctx, torch = env
+    rng = np.random.default_rng(77)
+    seen_pair = 0
+    for case, (k, n) in enumerate([(1, 8192), (2, 4096), (2, 70000), (3, 12288), (5, 65536 + 17), (8, 1 << 20),
+                                   (16, (1 << 20) + 4095), (16, 1 << 22), (24, 300000), (31, 262144), (48, 1 << 19)]):
+        w = rng.random(k) ** (1 + case % 3)
+        data = rng.choice(k, size=n, p=w / w.sum()).astype(np.uint8)
+        data = (data * np.uint8(7) + np.uint8(case)).astype(np.uint8)  # not just the low byte values
+        d_in = to_dev(torch, data)
+        idx = ctx.index_alloc(n)
+        d_out, nbytes, d_code = ctx.compress(d_in, index=idx)
+        ctx.sync()
+        nb = int(nbytes.item())
+        ref = orc.compress(data)
+        assert nb == ref.size and np.array_equal(d_out[:nb].cpu().numpy(), ref), (k, n)
+        seen_pair += ctx.code_to_host(d_code).max_len <= 6
+        back, nout = ctx.decode(d_out, nb, d_code, idx)
+        ctx.sync()
+        assert int(nout.item()) == n and np.array_equal(back[:n].cpu().numpy(), data), (k, n)
+        out2, n2 = ctx.decode(d_out, nb, d_code, None, cap=n + 64)
+        ctx.sync()
+        assert int(n2.item()) == n and np.array_equal(out2[:n].cpu().numpy(), data), (k, n, "foreign")
+        if n >= 65536 and k >= 3:
+            bad = d_out.clone()
+            bad[nb // 2] ^= 0x10
+            got, _ = ctx.decode(bad, nb, d_code, idx)
+            try:
+                ctx.sync()
+                flagged = False
+            except ghf.GhfError as e:
+                flagged = e.status == 7
+            # a flipped bit either breaks a segment boundary check (reported) or stays inside one segment with the
+            # same total length (possible only for equal-length codes): then exactly that segment differs
+            if not flagged:
+                diff = np.nonzero(got[:n].cpu().numpy() != data)[0]
+                assert diff.size and diff.max() - diff.min() < 64, (k, n)
+        ctx.index_free(idx)
+    assert seen_pair >= 5
