@@ -733,9 +733,15 @@ __device__ __forceinline__ void or_unit_words(uint4* unit, const uint32_t* st4, 
 
 // pack this lane's items at staging bit `sb`; lanes with active == false do nothing.
 // pass_total = bits of all active lanes; is_first_lane marks the lowest active lane.
-template <int N>
+// DRAIN (main loop only): right before the first global store of the tile, wait until at most ONE vector-memory
+// operation is outstanding.  In program order the outstanding ones are: the load of tile t+1 (issued two tiles ago),
+// the stores of tile t-1, the load of tile t+2 (issued when this tile started) -- so this guarantees tile t+1's data
+// and retires the old stores while tile t+2 stays in flight.  Without it the compiler has to derive its waits from
+// a store count it cannot know (the copy-out is a loop) and falls back to waiting for (almost) everything, i.e. for
+// this tile's own stores, before the next tile may touch its input.
+template <int N, bool DRAIN>
 __device__ __forceinline__ void pack_pass(WaveOut& W, const Items<N>& it, bool active, uint32_t sb, uint32_t pass_total,
-                                          bool is_first_lane, int lane) {
+                                          bool is_first_lane, int lane, uint32_t* seg_out, uint32_t seg_val) {
   uint32_t* st = W.st;
   uint32_t w = sb >> 5;
   uint32_t nb = sb & 31u;
@@ -771,6 +777,8 @@ __device__ __forceinline__ void pack_pass(WaveOut& W, const Items<N>& it, bool a
   // write the completed 16-byte units, carry the incomplete one
   const uint32_t endbits = W.carry + pass_total;
   const uint32_t U = endbits >> 7;
+  if (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F71);  // vmcnt(1)
+  if (seg_out) *seg_out = seg_val;
   for (uint32_t j = lane; j < U; j += 64) {
     uint4 v = *reinterpret_cast<const uint4*>(&st[4 * j]);
     v.x = bswap32(v.x); v.y = bswap32(v.y); v.z = bswap32(v.z); v.w = bswap32(v.w);
@@ -804,7 +812,7 @@ __device__ __forceinline__ void pack_pass(WaveOut& W, const Items<N>& it, bool a
 }
 
 // one wave iteration: items of every lane -> bits in the staging area -> whole units to HBM
-template <int N>
+template <int N, bool DRAIN>
 __device__ __forceinline__ void emit_iteration(WaveOut& W, const Items<N>& it, int lane, uint32_t* seg_out, uint64_t relbits,
                                                bool seg_valid, uint32_t& total_out) {
   uint32_t T = 0;
@@ -814,7 +822,7 @@ __device__ __forceinline__ void emit_iteration(WaveOut& W, const Items<N>& it, i
   const uint32_t excl = incl - T;
   const uint32_t total = __shfl(incl, 63, 64);
   total_out = total;
-  if (seg_out && seg_valid && (lane & 3) == 0) *seg_out = (uint32_t)(relbits + excl);
+  uint32_t* const seg_dst = (seg_out && seg_valid && (lane & 3) == 0) ? seg_out : nullptr;  // stored with the tile's units
   // normally one pass; only with long codes (> 16 bits on average) the 1024 symbols are packed as two half-waves,
   // each at most 512 x 32 bits, so the staging area never overflows
   const bool split = W.carry + total + 128u > (uint32_t)kStageCapBits;
@@ -825,7 +833,8 @@ __device__ __forceinline__ void emit_iteration(WaveOut& W, const Items<N>& it, i
     const bool active = !split || ((lane >= 32) == second);
     const uint32_t base = second ? half_total : 0u;
     const uint32_t ptotal = split ? (second ? total - half_total : half_total) : total;
-    pack_pass<N>(W, it, active, W.carry + (excl - base), ptotal, lane == (second ? 32 : 0), lane);
+    pack_pass<N, DRAIN>(W, it, active, W.carry + (excl - base), ptotal, lane == (second ? 32 : 0), lane,
+                        p == 0 ? seg_dst : nullptr, (uint32_t)(relbits + excl));
   }
 }
 
@@ -874,6 +883,7 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, cons
   //      its load is pending (the last prefetches are clamped to the last full tile and simply unused).
   if (nfull >= 2) {
     uint4 A = pv[0], B = pv[64];
+    __builtin_amdgcn_s_waitcnt(0x0F71);  // vmcnt(1): A has arrived, so the loop is entered in the state its back edge leaves
     for (; it + 1 < nfull; it += 2) {
       {
         const uint4 v = A;
@@ -884,7 +894,7 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, cons
         Items<M::N> items;
         make_items<M>(e, items);
         uint32_t total;
-        emit_iteration<M::N>(W, items, lane, segp ? segp + it * 16 : nullptr, relbits, true, total);
+        emit_iteration<M::N, true>(W, items, lane, segp ? segp + it * 16 : nullptr, relbits, true, total);
         relbits += total;
       }
       {
@@ -896,7 +906,7 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, cons
         Items<M::N> items;
         make_items<M>(e, items);
         uint32_t total;
-        emit_iteration<M::N>(W, items, lane, segp ? segp + (it + 1) * 16 : nullptr, relbits, true, total);
+        emit_iteration<M::N, true>(W, items, lane, segp ? segp + (it + 1) * 16 : nullptr, relbits, true, total);
         relbits += total;
       }
     }
@@ -950,7 +960,7 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, cons
       }
     }
     uint32_t total;
-    emit_iteration<M::N>(W, items, lane, seg_out, relbits, seg_valid, total);
+    emit_iteration<M::N, false>(W, items, lane, seg_out, relbits, seg_valid, total);
     relbits += total;
   }
   // the chunk's last, incomplete unit is shared with the next chunk (or is the end of the stream)
@@ -1138,9 +1148,9 @@ struct DecLds {  // K6 (side-car reconstruction): 4 waves, plain table
 // table gets a fixed 32 KiB; with lut_bits index bits there is room for R = 2^(14 - lut_bits) copies, lane l uses
 // copy l % R:  9-bit codes (uniform bytes) -> 32 copies, every lane of a 32-lane LDS group in its own bank pair;
 // 12-bit tables -> 4 copies (skewed data hits few, mostly identical entries anyway: identical addresses broadcast).
-constexpr int kDec7Threads = 512;
+constexpr int kDec7Threads = 1024;
 constexpr int kDec7Waves = kDec7Threads / kWave;
-constexpr int kDec7LutLog2 = 12;
+constexpr int kDec7LutLog2 = 13;
 constexpr int kDec7InBytes = 4608;  // staged span per wave: 4096 symbols at <= 9 bits average (a byte-Huffman code averages <= 8.1)
 constexpr int kDec7InWords = kDec7InBytes / 4;
 struct DecLds7 {
@@ -1152,7 +1162,7 @@ struct DecLds7 {
   uint16_t symbol[GHF_NSYM + 3];
   int status0;
 };
-static_assert(sizeof(DecLds7) <= 80 * 1024, "two workgroups per CU");
+static_assert(sizeof(DecLds7) <= 160 * 1024, "one workgroup of 16 waves per CU");
 
 template <typename LT>
 __device__ __forceinline__ void dec_small_load(LT& L, const DecTables* dt, int tid, int nthreads) {
@@ -1292,12 +1302,8 @@ __device__ __forceinline__ uint32_t decode_segment(const LT& L, const DecIn<STAG
         bad2 |= ea | eb;
         wq[k] = __builtin_amdgcn_perm(eb, ea, 0x05040100u);  // {ea.sym0, ea.sym1, eb.sym0, eb.sym1}
       }
-#if defined(GHF_EXP) && (GHF_EXP == 2 || GHF_EXP == 9)
-      if (valid && wq[0] == 0x12345678u && wq[1] == 0x9abcdef0u) store16_untracked(optr + q * 16, wq[0], wq[1], wq[2], wq[3]);
-#else
       if (LDSOUT) *reinterpret_cast<uint4*>(outl + (((uint32_t)q ^ osw) << 2)) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
       else if (valid) *reinterpret_cast<uint4*>(optr + q * 16) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
-#endif
     }
     bad_acc |= (bad2 >> 22) & 256u;
   } else if (STAGED && all_full) {
@@ -1322,12 +1328,8 @@ __device__ __forceinline__ uint32_t decode_segment(const LT& L, const DecIn<STAG
         const uint32_t hi = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0400u);
         wq[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
       }
-#if defined(GHF_EXP) && (GHF_EXP == 2 || GHF_EXP == 9)
-      if (valid && wq[0] == 0x12345678u && wq[1] == 0x9abcdef0u) store16_untracked(optr + q * 16, wq[0], wq[1], wq[2], wq[3]);
-#else
       if (LDSOUT) *reinterpret_cast<uint4*>(outl + (((uint32_t)q ^ osw) << 2)) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
       else if (valid) *reinterpret_cast<uint4*>(optr + q * 16) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
-#endif
     }
   } else if (valid) {
     for (uint32_t i = 0; i < cnt; ++i) {
@@ -1548,6 +1550,9 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
           const uint32_t sl = (uint32_t)r * 16 + ((uint32_t)lane >> 2);        // the lane whose row holds my piece
           const uint32_t piece = ((uint32_t)lane & 3u) ^ ((sl >> 2) & 3u);
           const uint4 v = *reinterpret_cast<const uint4*>(ot + sl * 16 + piece * 4);
+#if defined(GHF_EXP) && (GHF_EXP == 2 || GHF_EXP == 9)
+          if (v.x == 0x12345678u && v.y == 0x9abcdef0u)  // experiment: no output stores
+#endif
           *reinterpret_cast<uint4*>(og + r * 1024) = v;
         }
       }
@@ -1609,7 +1614,7 @@ void launch_decode(const DecParams& p, hipStream_t s) {
   const uint64_t groups = (p.n_segs + 63) / 64;
   uint64_t blocks = (groups + kDec7Waves - 1) / kDec7Waves;
   if (blocks == 0) return;
-  if (blocks > 256 * 2) blocks = 256 * 2;  // persistent: 2 workgroups of 8 waves per CU fit the LDS
+  if (blocks > 256) blocks = 256;  // persistent: one workgroup of 16 waves per CU (its LDS tiles + table take 155 KiB)
   hipLaunchKernelGGL(k_decode, dim3((uint32_t)blocks), dim3(kDec7Threads), 0, s, p);
 }
 
