@@ -330,3 +330,74 @@ def test_small_alphabets_two_symbols_per_lookup(env):
                 assert diff.size and diff.max() - diff.min() < 64, (k, n)
         ctx.index_free(idx)
     assert seen_pair >= 5
+
+
+@pytest.mark.parametrize("kind,n", [("zipf", 1 << 32), ("sym16", 1 << 32), ("uniform", (1 << 32) + 4099)])
+def test_baseline_configs_4GiB_properties(env, kind, n):
+    """BASELINE configs 3 and 5 (4 GiB Zipf encode, 4 GiB 16-symbol decode) and a > 4 GiB uniform stream (64-bit
+    offsets everywhere), generated on the device.  Size-independent properties only: exact histogram, tables ==
+    oracle(histogram), stream size == header + ceil(sum freq*len / 8), first MiB of the body == the oracle's packer,
+    exact round trip with the side-car, padding bits."""
+    ghf, ctx, torch = env
+    import ctypes as C
+    import importlib
+    pkgload.load()
+    synth = importlib.import_module("golden_huffman_amd.synth")
+    d_in = synth.make(torch, kind, n, device="cuda", seed=7)
+    idx = ctx.index_alloc(n)
+    out = ctx.empty_u8(ghf.compress_bound(n))
+    d_out, nbytes, d_code = ctx.compress(d_in, d_out=out, index=idx)
+    ctx.sync()
+    nb = int(nbytes.item())
+    hist = torch.zeros(256, dtype=torch.int64, device="cuda")
+    for lo in range(0, n, 1 << 30):
+        hist += torch.bincount(d_in[lo : lo + (1 << 30)].to(torch.int32), minlength=256)
+    hist = np.concatenate([hist.cpu().numpy(), [1]]).astype(np.int64)
+    assert ctx.histogram(d_in).cpu().numpy().tolist() == hist.tolist()
+    ocode = orc.build_code(hist)
+    assert ctx.code_to_host(d_code).as_dict() == ocode.as_dict()
+    hs = 1040 + 8 * ocode.max_len
+    bits = orc.body_bits(hist, ocode)
+    assert nb == hs + (bits + 7) // 8
+    m = 1 << 20
+    head = d_out[: hs + 2 * m + 64].cpu().numpy()
+    assert np.array_equal(head[:hs], orc.header_bytes(ocode))
+    first = d_in[:m].cpu().numpy()
+    buf = np.zeros(2 * m + 64, dtype=np.uint8)
+    orc.lib().orc_encode_body(first.ctypes.data, m, C.byref(ocode), buf.ctypes.data, buf.size)
+    pbits = int(np.array(list(ocode.length), dtype=np.int64)[first].sum())
+    assert np.array_equal(head[hs : hs + pbits // 8], buf[: pbits // 8])
+    back, nout = ctx.decode(d_out, nb, d_code, idx)
+    ctx.sync()
+    assert int(nout.item()) == n
+    for lo in range(0, n, 1 << 30):
+        assert bool((back[lo : lo + (1 << 30)] == d_in[lo : lo + (1 << 30)]).all().item()), lo
+    pad = (8 - bits % 8) % 8
+    assert int(d_out[nb - 1].item()) & ((1 << pad) - 1) == (1 << pad) - 1
+    ctx.index_free(idx)
+    del d_in, out, back, d_out
+    torch.cuda.empty_cache()
+
+
+def test_nonstationary_stream_takes_the_unstaged_path(env):
+    """A run of rare symbols (12+ bit codes) inside a stream of one frequent symbol: the groups in the run span
+    more compressed bytes than K7's LDS tile holds, so they are decoded by the unstaged fallback, next to
+    ordinary groups; also through K6 (no side-car)."""
+    ghf, ctx, torch = env
+    rng = np.random.default_rng(11)
+    # five frequent symbols with halving frequencies push the 200 rare ones below depth 5: 13-bit codes
+    data = rng.choice(np.array([65, 66, 67, 68, 69], dtype=np.uint8), size=3 << 20, p=[16 / 31, 8 / 31, 4 / 31, 2 / 31, 1 / 31])
+    run = rng.integers(100, 300, size=96 * 1024).astype(np.uint8)  # 200 rare symbols (wraps past 255: 100..255, 0..43)
+    data[(1 << 20) + 777 : (1 << 20) + 777 + run.size] = run
+    _, d_out, nb, d_code, idx = run_compress(ghf, ctx, torch, data)
+    ref = orc.compress(data)
+    assert nb == ref.size and np.array_equal(d_out[:nb].cpu().numpy(), ref)
+    code = ctx.code_to_host(d_code)
+    assert min(code.length[int(s)] for s in set(run.tolist())) >= 10  # 4096 of them do not fit 4608 bytes
+    back, nout = ctx.decode(d_out, nb, d_code, idx)
+    ctx.sync()
+    assert int(nout.item()) == data.size and np.array_equal(back[: data.size].cpu().numpy(), data)
+    out2, n2 = ctx.decode(d_out, nb, d_code, None, cap=data.size + 64)
+    ctx.sync()
+    assert int(n2.item()) == data.size and np.array_equal(out2[: data.size].cpu().numpy(), data)
+    ctx.index_free(idx)
