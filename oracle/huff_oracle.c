@@ -337,3 +337,185 @@ int orc_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t
   if (!hs) return -4;
   return orc_decode_body(in + hs, n - hs, &c, out, cap, out_n);
 }
+
+/* ================================================================== SURVEY 8(f) N3: the .crs format
+ * (NormalHuffEncoder / NormalHuffDecoder, include/normal_huff_encoder.h + include/huff_tree.{h,cc}).
+ * Same test-infrastructure status as everything above; pinned by tests/golden/golden_crs.json, which
+ * the compiled reference (ref_glzip nc/nd/nt) produced. */
+
+/* include/huff_tree.h:228-235 (init_queue: keys 0..255 ascending, zero counts skipped; no end mark) and
+ * include/huff_tree.cc:138-153 (build_tree: left = first popped, right = second popped, push the parent).
+ * The queue is std::priority_queue<Node*, deque<Node*>, HuffNodePtrGreater> (huff_tree.h:190-201): the same
+ * libstdc++ heap on weight only as above.  Nodes 0..255 are the leaves (by key), 256+t is the t-th parent. */
+int orc_crs_build_tree(const int64_t hist256[256], orc_tree* t) {
+  int64_t w[ORC_CRS_NODES];
+  orc_heap h;
+  h.n = 0;
+  h.f = w;
+  memset(t, 0, sizeof(*t));
+  for (int i = 0; i < ORC_CRS_NODES; i++) t->left[i] = t->right[i] = -1;
+  for (int i = 0; i < 256; i++) {
+    w[i] = hist256[i];
+    if (hist256[i]) {
+      heap_push(&h, i);
+      t->n_leaves++;
+    }
+  }
+  if (t->n_leaves == 0) return -1; /* empty input: pqueue_.top() on an empty queue, undefined */
+  int times = h.n - 1;
+  for (int k = 0; k < times; k++) {
+    int l = h.a[0];
+    heap_pop(&h);
+    int r = h.a[0];
+    heap_pop(&h);
+    int p = 256 + k;
+    t->left[p] = l;
+    t->right[p] = r;
+    w[p] = w[l] + w[r]; /* huff_tree.h:62-66 */
+    heap_push(&h, p);
+  }
+  t->root = h.a[0];
+  t->n_nodes = 2 * t->n_leaves - 1;
+  return t->n_leaves == 1 ? -3 : 0; /* a lone leaf gets the empty code: the reference's decoder then dereferences NULL */
+}
+
+/* include/huff_tree.cc:158-171 (do_gen_encode: '0' to the left, '1' to the right, preorder) */
+static void crs_codes_rec(const orc_tree* t, int node, uint8_t* path, int depth, orc_crs_code* c) {
+  if (t->left[node] < 0) {
+    c->len[node] = (uint16_t)depth;
+    memcpy(c->bits[node], path, (size_t)depth);
+    return;
+  }
+  path[depth] = 0;
+  crs_codes_rec(t, t->left[node], path, depth + 1, c);
+  path[depth] = 1;
+  crs_codes_rec(t, t->right[node], path, depth + 1, c);
+}
+
+void orc_crs_codes(const orc_tree* t, orc_crs_code* c) {
+  uint8_t path[256];
+  memset(c, 0, sizeof(*c));
+  crs_codes_rec(t, t->root, path, 0, c);
+}
+
+/* include/huff_tree.cc:174-187 (do_serialize_tree): preorder, two bytes per node: (0, key) / (255, 255) */
+static uint8_t* crs_ser_rec(const orc_tree* t, int node, uint8_t* p) {
+  if (t->left[node] < 0) {
+    *p++ = 0;
+    *p++ = (uint8_t)node;
+    return p;
+  }
+  *p++ = 255;
+  *p++ = 255;
+  p = crs_ser_rec(t, t->left[node], p);
+  return crs_ser_rec(t, t->right[node], p);
+}
+
+size_t orc_crs_write_tree(const orc_tree* t, uint8_t* out) { return (size_t)(crs_ser_rec(t, t->root, out) - out); }
+
+size_t orc_crs_bound(size_t n) { return 2 * 511 + 2 + n + n / 4 + 64; } /* byte Huffman averages < 9 bits */
+
+/* Compressor<NormalHuffEncoder<>>::compress(), include/compressor.h:62-73 with
+ * include/normal_huff_encoder.h:136-138 (tree first) and :159-186 (two placeholder bytes, every code MSB-first,
+ * then -- if the last byte is incomplete -- {left_bits, last byte zero-filled} go back into the placeholders;
+ * the body keeps whole bytes only, utils/include/buffer.h:233-247,277-280). returns 0, -1 empty, -3 single symbol */
+int orc_crs_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_n) {
+  int64_t hist[256];
+  memset(hist, 0, sizeof(hist));
+  for (size_t i = 0; i < n; i++) hist[in[i]]++; /* include/encoder.h:136-150 */
+  orc_tree t;
+  int rc = orc_crs_build_tree(hist, &t);
+  if (rc) return rc;
+  static orc_crs_code c; /* 64 KiB: not on the stack */
+  orc_crs_codes(&t, &c);
+  if (cap < 2 * (size_t)t.n_nodes + 2) return -2;
+  size_t hs = orc_crs_write_tree(&t, out);
+  uint8_t* body = out + hs + 2;
+  size_t nb = 0;
+  unsigned acc = 0, k = 0;
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t* b = c.bits[in[i]];
+    for (unsigned j = 0; j < c.len[in[i]]; j++) {
+      acc = (acc << 1) | b[j];
+      if (++k == 8) {
+        if (hs + 2 + nb >= cap) return -2;
+        body[nb++] = (uint8_t)acc;
+        acc = 0;
+        k = 0;
+      }
+    }
+  }
+  unsigned left = (8 - k) % 8;
+  out[hs] = (uint8_t)left;
+  out[hs + 1] = left ? (uint8_t)(acc << left) : 0;
+  *out_n = hs + 2 + nb;
+  return 0;
+}
+
+/* include/huff_tree.cc:289-303 (do_build_tree: preorder, first byte 0 = leaf) -- with the bounds checks the
+ * reference lacks.  returns header bytes, 0 on a malformed/truncated tree. */
+static int crs_parse_rec(const uint8_t* in, size_t n, size_t* pos, orc_tree* t, int* next_internal, int depth) {
+  if (*pos + 2 > n || depth > 256) return -1;
+  uint8_t first = in[*pos], second = in[*pos + 1];
+  *pos += 2;
+  if (first == 0) {
+    t->n_leaves++;
+    return second;
+  }
+  if (*next_internal >= ORC_CRS_NODES) return -1;
+  int p = (*next_internal)++;
+  int l = crs_parse_rec(in, n, pos, t, next_internal, depth + 1);
+  if (l < 0) return -1;
+  int r = crs_parse_rec(in, n, pos, t, next_internal, depth + 1);
+  if (r < 0) return -1;
+  t->left[p] = l;
+  t->right[p] = r;
+  return p;
+}
+
+size_t orc_crs_parse_tree(const uint8_t* in, size_t n, orc_tree* t) {
+  memset(t, 0, sizeof(*t));
+  for (int i = 0; i < ORC_CRS_NODES; i++) t->left[i] = t->right[i] = -1;
+  size_t pos = 0;
+  int next_internal = 256;
+  int root = crs_parse_rec(in, n, &pos, t, &next_internal, 0);
+  if (root < 0) return 0;
+  t->root = root;
+  t->n_nodes = 2 * t->n_leaves - 1;
+  return pos;
+}
+
+/* Decompressor<NormalHuffDecoder<>>::decompress(): include/huff_tree.cc:191-207 (two prefix bytes, every body byte
+ * bit by bit from the MSB, then 8 - left_bit bits of the stored last byte) and :255-271 (decode_byte: walk, emit at
+ * a leaf, restart at the root).  returns 0, -1 malformed, -2 cap, -3 root is a leaf (reference: NULL dereference) */
+int orc_crs_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_n) {
+  orc_tree t;
+  size_t hs = orc_crs_parse_tree(in, n, &t);
+  if (!hs || hs + 2 > n) return -1;
+  if (t.left[t.root] < 0) return -3;
+  unsigned left = in[hs], last = in[hs + 1];
+  if (left > 7) return -1;
+  size_t no = 0;
+  int cur = t.root;
+  for (size_t i = hs + 2; i <= n; i++) {
+    unsigned byte, nbits;
+    if (i < n) {
+      byte = in[i];
+      nbits = 8;
+    } else {
+      if (!left) break;
+      byte = last;
+      nbits = 8 - left;
+    }
+    for (unsigned b = 0; b < nbits; b++) {
+      cur = ((byte >> (7 - b)) & 1) ? t.right[cur] : t.left[cur];
+      if (t.left[cur] < 0) {
+        if (no >= cap) return -2;
+        out[no++] = (uint8_t)cur;
+        cur = t.root;
+      }
+    }
+  }
+  *out_n = no;
+  return 0;
+}

@@ -71,6 +71,26 @@ uint64_t orc_pack_at(const uint8_t* in, size_t n, const orc_code* c, unsigned ph
 /* total body bits incl. the EOF code, before padding */
 uint64_t orc_body_bits(const int64_t hist[ORC_NSYM], const orc_code* c);
 
+/* ---------------------------------------------------------------- the .crs format
+ * (include/normal_huff_encoder.h, include/huff_tree.h, include/huff_tree.cc) */
+#define ORC_CRS_NODES 512 /* 256 leaves (node id = key) + up to 255 parents (256 + creation order) */
+typedef struct orc_tree {
+  int left[ORC_CRS_NODES], right[ORC_CRS_NODES]; /* -1 at leaves */
+  int root, n_leaves, n_nodes;
+} orc_tree;
+typedef struct orc_crs_code {
+  uint16_t len[256];
+  uint8_t bits[256][256]; /* one 0/1 per code bit, root first (the reference keeps std::string codes) */
+} orc_crs_code;
+
+int orc_crs_build_tree(const int64_t hist256[256], orc_tree* t);
+void orc_crs_codes(const orc_tree* t, orc_crs_code* c);
+size_t orc_crs_write_tree(const orc_tree* t, uint8_t* out);
+size_t orc_crs_parse_tree(const uint8_t* in, size_t n, orc_tree* t);
+size_t orc_crs_bound(size_t n);
+int orc_crs_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_n);
+int orc_crs_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,16 @@ class OrcCode(C.Structure):
         }
 
 
+class OrcTree(C.Structure):
+    """mirror of orc_tree: the reference's HuffTree (include/huff_tree.h:41-98), leaves = node ids 0..255."""
+
+    _fields_ = [("left", C.c_int * 512), ("right", C.c_int * 512), ("root", C.c_int), ("n_leaves", C.c_int), ("n_nodes", C.c_int)]
+
+
+class OrcCrsCode(C.Structure):
+    _fields_ = [("len", C.c_uint16 * 256), ("bits", (C.c_uint8 * 256) * 256)]
+
+
 def build():
     """(re)build liboracle.so -- and the reference driver when /root/reference is present."""
     subprocess.run(["make", "-s", "-C", HERE, "all"], check=True)
@@ -86,6 +96,20 @@ def lib():
         L.orc_pack_at.restype = C.c_uint64
         L.orc_body_bits.argtypes = [C.POINTER(C.c_int64), C.POINTER(OrcCode)]
         L.orc_body_bits.restype = C.c_uint64
+        L.orc_crs_build_tree.argtypes = [C.POINTER(C.c_int64), C.POINTER(OrcTree)]
+        L.orc_crs_build_tree.restype = C.c_int
+        L.orc_crs_codes.argtypes = [C.POINTER(OrcTree), C.POINTER(OrcCrsCode)]
+        L.orc_crs_codes.restype = None
+        L.orc_crs_write_tree.argtypes = [C.POINTER(OrcTree), u8p]
+        L.orc_crs_write_tree.restype = C.c_size_t
+        L.orc_crs_parse_tree.argtypes = [u8p, C.c_size_t, C.POINTER(OrcTree)]
+        L.orc_crs_parse_tree.restype = C.c_size_t
+        L.orc_crs_bound.argtypes = [C.c_size_t]
+        L.orc_crs_bound.restype = C.c_size_t
+        L.orc_crs_compress.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_crs_compress.restype = C.c_int
+        L.orc_crs_decompress.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.orc_crs_decompress.restype = C.c_int
         _lib = L
     return _lib
 
@@ -154,6 +178,52 @@ def parse_header(crs2):
     if not hs:
         raise ValueError("bad .crs2 header")
     return c, hs
+
+
+# ------------------------------------------------------------------ .crs (NormalHuffEncoder)
+def crs_tree(hist256):
+    h = np.ascontiguousarray(hist256[:256], dtype=np.int64)
+    t = OrcTree()
+    rc = lib().orc_crs_build_tree(h.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(t))
+    if rc:
+        raise ValueError("orc_crs_build_tree rc=%d" % rc)
+    return t
+
+
+def crs_code_strings(tree):
+    """the 256 code strings ('0'/'1'), '' for absent symbols -- what NormalHuffEncoder::encode_map_ holds."""
+    c = OrcCrsCode()
+    lib().orc_crs_codes(C.byref(tree), C.byref(c))
+    return ["".join("01"[b] for b in c.bits[s][: c.len[s]]) for s in range(256)]
+
+
+def crs_tree_bytes(tree):
+    out = np.zeros(2 * 511, dtype=np.uint8)
+    n = lib().orc_crs_write_tree(C.byref(tree), out.ctypes.data)
+    return out[:n].copy()
+
+
+def crs_compress(data):
+    a, p = _u8(data)
+    cap = lib().orc_crs_bound(a.size)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().orc_crs_compress(p, a.size, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        raise ValueError("orc_crs_compress rc=%d" % rc)
+    return out[: n.value].copy()
+
+
+def crs_decompress(crs, cap=None):
+    a, p = _u8(crs)
+    if cap is None:
+        cap = a.size * 8 + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().orc_crs_decompress(p, a.size, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        raise ValueError("orc_crs_decompress rc=%d" % rc)
+    return out[: n.value].copy()
 
 
 # ------------------------------------------------------------------ the compiled reference (build container only)

@@ -17,6 +17,10 @@
 //         ref_glzip df <in.crs2> <out>     decompress, FastCanonicalHuffDecoder   (run under timeout!)
 //         ref_glzip t  <in>                dump stage tables as JSON on stdout (also writes <in>.crs2.tmp, removed)
 //         ref_glzip b  <in> <out.crs2> <out.de>   time every phase, JSON on stdout
+// SURVEY 8(f) N3, the .crs format (include/normal_huff_encoder.h, include/huff_tree.cc):
+//         ref_glzip nc <in> <out.crs>      Compressor<NormalHuffEncoder<> >
+//         ref_glzip nd <in.crs> <out>      Decompressor<NormalHuffDecoder<> >
+//         ref_glzip nt <in>                dump the tree-order code strings as JSON on stdout
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -41,6 +45,7 @@
 #define protected public
 #include "compressor.h"
 #include "canonical_huff_encoder.h"
+#include "normal_huff_encoder.h"
 #undef private
 #undef protected
 
@@ -82,6 +87,31 @@ int main(int argc, char** argv) {
   if (mode == "df") {
     Decompressor<FastCanonicalHuffDecoder<> > d(in, out);
     d.decompress();
+    return 0;
+  }
+  if (mode == "nc") {
+    Compressor<NormalHuffEncoder<> > c;
+    c.set_file(in, out);
+    c.compress();
+    c.clear();
+    return 0;
+  }
+  if (mode == "nd") {
+    Decompressor<NormalHuffDecoder<> > d(in, out);
+    d.decompress();
+    return 0;
+  }
+  if (mode == "nt") {
+    std::string tmp = in + ".crs.tmp";
+    NormalHuffEncoder<> e;
+    e.set_file(in, tmp);
+    e.caculate_frequency();
+    e.gen_encode();
+    printf("{\"codes\": [");
+    for (int i = 0; i < 256; i++) printf("%s\"%s\"", i ? "," : "", e.encode_map_[i].c_str());
+    printf("]}\n");
+    e.clear();
+    remove(tmp.c_str());
     return 0;
   }
   if (mode == "t") {

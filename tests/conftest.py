@@ -20,3 +20,11 @@ def golden():
 
     with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
         return json.load(f)["cases"]
+
+
+@pytest.fixture(scope="session")
+def golden_crs():
+    import json
+
+    with open(os.path.join(ROOT, "tests", "golden", "golden_crs.json")) as f:
+        return json.load(f)["cases"]
