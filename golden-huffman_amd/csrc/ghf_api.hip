@@ -31,6 +31,7 @@ struct ghf_ctx {
   uint64_t* d_hist = nullptr;   // [257]
   uint64_t* d_hist_acc = nullptr;  // K1's replicated totals + arrival counter, zero between launches
   ghf_code* d_code = nullptr;   // scratch tables for ghf_compress
+  ghf_tree* d_tree = nullptr;   // scratch tree for ghf_crs_compress
   DecTables* d_dt = nullptr;
   uint64_t* d_u64 = nullptr;    // [8] scratch scalars: 0 total_bits, 1..2 end, 3 n_symbols, 4 eof_sub, 5 changed
   uint64_t* h_u64 = nullptr;    // [8] pinned mirror
@@ -104,9 +105,10 @@ const char* ghf_status_string(int s) {
     case GHF_E_EMPTY: return "empty input (undefined in the reference)";
     case GHF_E_CODELEN: return "code longer than 32 bits (reference limit)";
     case GHF_E_CAP: return "output capacity too small";
-    case GHF_E_FORMAT: return "not a .crs2 header";
+    case GHF_E_FORMAT: return "not a .crs2 / .crs header";
     case GHF_E_CORRUPT: return "corrupt stream";
     case GHF_E_NOMEM: return "out of memory";
+    case GHF_E_SINGLE: return "one distinct byte value (.crs: undefined in the reference)";
     default: return "unknown status";
   }
 }
@@ -138,6 +140,7 @@ int ghf_ctx_create(int device, ghf_ctx** out) {
   GHF_STEP(hipMalloc(&c->d_hist_acc, kHistAccWords * sizeof(uint64_t)));
   GHF_STEP(hipMemset(c->d_hist_acc, 0, kHistAccWords * sizeof(uint64_t)));
   GHF_STEP(hipMalloc(&c->d_code, sizeof(ghf_code)));
+  GHF_STEP(hipMalloc(&c->d_tree, sizeof(ghf_tree)));
   GHF_STEP(hipMalloc(&c->d_dt, sizeof(DecTables)));
   GHF_STEP(hipMalloc(&c->d_u64, 8 * sizeof(uint64_t)));
   GHF_STEP(hipHostMalloc(&c->h_u64, 8 * sizeof(uint64_t), hipHostMallocDefault));
@@ -164,6 +167,7 @@ int ghf_ctx_destroy(ghf_ctx* c) {
   if (c->d_hist) (void)hipFree(c->d_hist);
   if (c->d_hist_acc) (void)hipFree(c->d_hist_acc);
   if (c->d_code) (void)hipFree(c->d_code);
+  if (c->d_tree) (void)hipFree(c->d_tree);
   if (c->d_dt) (void)hipFree(c->d_dt);
   if (c->d_u64) (void)hipFree(c->d_u64);
   if (c->h_u64) (void)hipHostFree(c->h_u64);
@@ -477,6 +481,9 @@ int ghf_parse_header(const uint8_t* h, size_t n, ghf_code* code, size_t* header_
 
 // K6: rebuild the side-car of a stream that came without one (e.g. a .crs2 written by the reference).
 // Synchronises with the host a few times (convergence flag, symbol count); fills c->fidx.
+static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, size_t hdr, uint64_t end_bit, bool no_eof,
+                            size_t cap);
+
 static int rebuild_index(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code, size_t cap) {
   ghf_code* hc = new (std::nothrow) ghf_code;
   if (!hc) return GHF_E_NOMEM;
@@ -488,12 +495,21 @@ static int rebuild_index(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
   if (max_len < 1 || max_len > 32) return fail(c, GHF_E_FORMAT, "bad max_len in tables");
   const size_t hdr = ghf_header_bytes(max_len);
   if (stream_bytes <= hdr) return fail(c, GHF_E_FORMAT, "stream shorter than its header");
+  return rebuild_index_at(c, d_stream, stream_bytes, hdr, (uint64_t)stream_bytes * 8, false, cap);
+}
+
+// K6 driver.  hdr = bytes in front of the first code; end_bit = one past the last bit that may belong to a code;
+// no_eof: the stream has no end mark and must end exactly at end_bit (.crs)
+static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, size_t hdr, uint64_t end_bit, bool no_eof,
+                            size_t cap) {
   SyncParams p;
   p.stream = d_stream;
   p.stream_bytes = stream_bytes;
   p.body_bit0 = (uint64_t)hdr * 8;
+  p.end_bit = end_bit;
+  p.no_eof = no_eof ? 1u : 0u;
   p.dt = c->d_dt;
-  p.nsub = ((stream_bytes - hdr) * 8 + 511) / 512;
+  p.nsub = (end_bit - p.body_bit0 + 511) / 512;
   const size_t ntiles = (p.nsub + 255) / 256;
   // carve the workspace
   size_t off = 0;
@@ -522,7 +538,7 @@ static int rebuild_index(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
   GHF_HIP(c, hipMemsetAsync(p.start, 0, (p.nsub + 1) * 2, c->stream));
   GHF_HIP(c, hipMemsetAsync(p.used, 0xFF, p.nsub * 2, c->stream));
   GHF_HIP(c, hipMemsetAsync(p.eof, 0, p.nsub, c->stream));
-  launch_store_u64(p.eof_sub, nullptr, p.nsub, c->stream);
+  launch_store_u64(p.eof_sub, nullptr, p.nsub, c->stream);  // "none found"; k_sync_eof takes the minimum
   // passes until no boundary guess moves (self-synchronisation: a handful of passes in practice)
   for (uint64_t pass = 0;; ++pass) {
     if (pass > p.nsub + 2) return fail(c, GHF_E_CORRUPT, "self-synchronisation did not converge");
@@ -536,7 +552,13 @@ static int rebuild_index(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
   GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 3, c->d_u64 + 3, 16, hipMemcpyDeviceToHost, c->stream));
   GHF_HIP(c, hipStreamSynchronize(c->stream));
   const uint64_t n = c->h_u64[3], eof_sub = c->h_u64[4];
-  if (eof_sub >= p.nsub) return fail(c, GHF_E_CORRUPT, "no end mark in the stream");
+  if (no_eof) {
+    // every subsequence counts; a flagged one means bits that are no code or a code running past the end
+    // (eof_sub == nsub, "none", makes the counting kernels take every subsequence: n is already the total)
+    if (eof_sub < p.nsub) return fail(c, GHF_E_CORRUPT, "the .crs body does not end on a code boundary");
+  } else if (eof_sub >= p.nsub) {
+    return fail(c, GHF_E_CORRUPT, "no end mark in the stream");
+  }
   if (n > cap) return fail(c, GHF_E_CAP, "ghf_decode: output capacity below the decoded size");
   // size the side-car
   ghf_index& ix = c->fidx;
@@ -618,6 +640,176 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
   p.out_bytes = d_out_bytes;
   launch_decode(p, c->stream);
   if (d_out_bytes && index->n_symbols == 0) launch_store_u64(d_out_bytes, nullptr, 0, c->stream);  // no decode launch then
+  GHF_HIP(c, hipGetLastError());
+  return GHF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- .crs
+int ghf_crs_build_code(ghf_ctx* c, const uint64_t* d_hist, ghf_tree* d_tree, ghf_code* d_code) {
+  if (!c || !d_hist || !d_tree || !d_code) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  launch_crs_build_code(d_hist, d_tree, d_code, c->d_u64 + 6, c->d_status, c->stream);
+  GHF_HIP(c, hipGetLastError());
+  c->plan_in = nullptr;  // d_code changed: a cached plan no longer describes it
+  return GHF_OK;
+}
+
+size_t ghf_crs_compress_bound(size_t n) { return 1024 + 2 + ghf_compress_bound(n); }
+
+int ghf_crs_compress(ghf_ctx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes,
+                     ghf_tree* d_tree, const ghf_index* index) {
+  if (!c || !d_out || (n && !d_in)) return GHF_E_INVAL;
+  if (n == 0) return fail(c, GHF_E_EMPTY, "empty input is undefined in the reference; refused");
+  if (!aligned16(d_out)) return fail(c, GHF_E_INVAL, "d_out must be 16-byte aligned");
+  ghf_tree* tree = d_tree ? d_tree : c->d_tree;
+  int rc;
+  if ((rc = ghf_histogram(c, d_in, n, c->d_hist))) return rc;            // compressor.h:63
+  if ((rc = ghf_crs_build_code(c, c->d_hist, tree, c->d_code))) return rc;  // compressor.h:64, start bit -> d_u64[6]
+  if ((rc = ghf_encode_plan(c, d_in, n, c->d_code, c->d_u64))) return rc;
+  // compressor.h:72: the body right behind tree + two prefix bytes; no end mark, zero fill (flags = 0)
+  if ((rc = ghf_encode_emit(c, d_in, n, c->d_code, c->d_u64 + 6, 0, d_out, cap, index, c->d_u64 + 1))) return rc;
+  launch_crs_finish(tree, c->d_u64, d_out, d_out_bytes, c->d_status, c->stream);  // compressor.h:70 + normal_huff_encoder.h:176-184
+  GHF_HIP(c, hipGetLastError());
+  return GHF_OK;
+}
+
+// DecodeHuffTree::do_build_tree (include/huff_tree.cc:289-303), iteratively and with bounds
+int ghf_crs_parse_header(const uint8_t* h, size_t n, ghf_tree* tree, size_t* tree_bytes) {
+  if (!h || !tree) return GHF_E_INVAL;
+  std::memset(tree, 0, sizeof *tree);
+  struct Open {  // a parent that still waits for a child
+    uint16_t idx, depth;
+    bool has_left;
+  };
+  Open stack[260];
+  int sp = 0;
+  size_t pos = 0;
+  uint32_t n_parents = 0, n_leaves = 0, max_len = 0;
+  for (bool first_node = true;; first_node = false) {
+    if (pos + 2 > n || pos + 2 > sizeof tree->header) return GHF_E_FORMAT;
+    const bool leaf = h[pos] == 0;  // huff_tree.cc:294: first byte 0 = leaf, second byte = key
+    const uint32_t key = h[pos + 1];
+    pos += 2;
+    uint32_t id, depth = 0;
+    if (leaf) {
+      id = key;
+      ++n_leaves;
+    } else {
+      if (n_parents >= 255) return GHF_E_FORMAT;
+      id = 256 + n_parents++;
+    }
+    if (first_node) {
+      if (leaf) return GHF_E_FORMAT;  // the root is a leaf: the reference's decoder dereferences NULL there
+      tree->root = id;
+    } else {
+      Open& top = stack[sp - 1];
+      depth = top.depth + 1u;
+      if (!top.has_left) {
+        tree->left[top.idx] = (uint16_t)id;
+        top.has_left = true;
+      } else {
+        tree->right[top.idx] = (uint16_t)id;
+        --sp;
+      }
+    }
+    if (leaf) {
+      if (depth > max_len) max_len = depth;
+    } else {
+      if (sp >= 258) return GHF_E_FORMAT;
+      stack[sp].idx = (uint16_t)(id - 256);
+      stack[sp].depth = (uint16_t)depth;
+      stack[sp].has_left = false;
+      ++sp;
+    }
+    if (sp == 0) break;
+  }
+  if (n_leaves < 2 || n_leaves > 256 || n_parents != n_leaves - 1) return GHF_E_FORMAT;
+  if (max_len > 32) return GHF_E_CODELEN;
+  tree->n_leaves = n_leaves;
+  tree->max_len = max_len;
+  tree->tree_bytes = (uint32_t)pos;
+  std::memcpy(tree->header, h, pos);
+  if (tree_bytes) *tree_bytes = pos;
+  return GHF_OK;
+}
+
+static int crs_geometry(ghf_ctx* c, const ghf_tree* d_tree, size_t stream_bytes, int left_bits, size_t* hdr, uint64_t* end_bit) {
+  if (left_bits < 0 || left_bits > 7) return fail(c, GHF_E_FORMAT, "left_bits must be 0..7");
+  uint32_t tb = 0;
+  hipError_t e = hipMemcpyAsync(c->h_u64 + 7, &d_tree->tree_bytes, 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail(c, GHF_E_HIP, "copy tree_bytes to host", e);
+  std::memcpy(&tb, c->h_u64 + 7, 4);
+  if (tb < 6 || tb > 1022 || (tb & 1)) return fail(c, GHF_E_FORMAT, "bad tree_bytes");
+  *hdr = (size_t)tb + 2;
+  if (stream_bytes < *hdr || (left_bits && stream_bytes == *hdr)) return fail(c, GHF_E_FORMAT, "stream shorter than its header");
+  *end_bit = (uint64_t)stream_bytes * 8 - (uint64_t)left_bits;
+  return GHF_OK;
+}
+
+int ghf_crs_decoded_size(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int left_bits, const ghf_tree* d_tree,
+                         uint64_t* n_out) {
+  if (!c || !d_stream || !d_tree || !n_out) return GHF_E_INVAL;
+  if (!aligned16(d_stream)) return fail(c, GHF_E_INVAL, "d_stream must be 16-byte aligned");
+  GHF_HIP(c, hipSetDevice(c->device));
+  size_t hdr;
+  uint64_t end_bit;
+  int rc = crs_geometry(c, d_tree, stream_bytes, left_bits, &hdr, &end_bit);
+  if (rc) return rc;
+  launch_crs_decode_tables(d_tree, c->d_dt, c->d_status, c->stream);
+  if (end_bit == (uint64_t)hdr * 8) {  // an empty body decodes to nothing
+    *n_out = 0;
+    return GHF_OK;
+  }
+  rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, true, (size_t)-1);
+  if (rc) return rc;
+  *n_out = c->fidx.n_symbols;
+  return GHF_OK;
+}
+
+int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int left_bits, const ghf_tree* d_tree,
+                   const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes) {
+  if (!c || !d_stream || !d_tree || !d_out) return GHF_E_INVAL;
+  if (!aligned16(d_stream)) return fail(c, GHF_E_INVAL, "d_stream must be 16-byte aligned");
+  GHF_HIP(c, hipSetDevice(c->device));
+  launch_crs_decode_tables(d_tree, c->d_dt, c->d_status, c->stream);
+  if (!index) {
+    size_t hdr;
+    uint64_t end_bit;
+    int rc = crs_geometry(c, d_tree, stream_bytes, left_bits, &hdr, &end_bit);
+    if (rc) return rc;
+    if (end_bit == (uint64_t)hdr * 8) {
+      if (d_out_bytes) launch_store_u64(d_out_bytes, nullptr, 0, c->stream);
+      return GHF_OK;
+    }
+    if (c->fidx_stream != d_stream || c->fidx_bytes != stream_bytes) {
+      rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, true, cap);
+      if (rc) return rc;
+    }
+    c->fidx_stream = nullptr;
+    index = &c->fidx;
+  }
+  if (!index->d_chunk_bit || !index->d_seg_bit || index->seg_symbols != (uint32_t)kSegSymbols ||
+      (index->chunk_symbols & (index->chunk_symbols - 1)) || index->chunk_symbols < (uint32_t)kSegSymbols)
+    return fail(c, GHF_E_INVAL, "ghf_crs_decode: malformed index");
+  if (cap < index->n_symbols) return fail(c, GHF_E_CAP, "ghf_crs_decode: output capacity below n_symbols");
+  DecParams p;
+  p.stream = d_stream;
+  p.stream_bytes = stream_bytes;
+  p.dt = c->d_dt;
+  p.chunk_bit = index->d_chunk_bit;
+  p.seg_bit = index->d_seg_bit;
+  p.n_symbols = index->n_symbols;
+  p.n_segs = index->n_segs;
+  uint32_t cl = 0;
+  while ((1u << cl) < index->chunk_symbols) ++cl;
+  p.chunk_log2 = cl;
+  p.no_end_mark = 1u;  // there is none in this format; the end of every segment but the last is checked against the side-car
+  p.out = d_out;
+  p.status = c->d_status;
+  p.out_bytes = d_out_bytes;
+  launch_decode(p, c->stream);
+  if (d_out_bytes && index->n_symbols == 0) launch_store_u64(d_out_bytes, nullptr, 0, c->stream);
   GHF_HIP(c, hipGetLastError());
   return GHF_OK;
 }

@@ -47,6 +47,11 @@ struct DecTables {
   uint16_t symbol[GHF_NSYM + 3];
   int32_t min_len, max_len, lut_bits;
   int32_t pair_bits;       // 2 * max_len when that is <= kDecPairBitsMax (every pair of codes fits lut2's index), else 0
+  // kind 1 (.crs): the codes are whatever the tree says; codes beyond the direct table are decoded by
+  // walking tl/tr (children of parent i; ids < 256 = leaf key, else 256 + parent index) from `root`
+  int32_t kind;
+  uint32_t root;
+  uint16_t tl[256], tr[256];
   // work counters of k_decode, zeroed by k_build_decode_tables.  One word saturates at ~88 tickets/us (measured:
   // a single counter made the 256 MiB decode 4.8x slower), so the workgroups are split into 16 classes
   // (blockIdx % 16), each with its own counter on its own 128-byte line; class c owns the groups == c (mod 16).
@@ -94,6 +99,8 @@ struct SyncParams {
   const uint8_t* stream;
   uint64_t stream_bytes;
   uint64_t body_bit0;  // first body bit = 8 * header bytes
+  uint64_t end_bit;    // one past the last bit that may belong to a code (8 * stream_bytes for .crs2)
+  uint32_t no_eof;     // .crs: there is no end mark; the last code must end exactly at end_bit
   const DecTables* dt;
   uint64_t nsub;       // 512-bit subsequences covering the body
   uint16_t* start;     // [nsub + 1] current guess: bit offset of the first code boundary inside each subsequence
@@ -122,6 +129,11 @@ void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t 
 void launch_emit(const EmitParams& p, hipStream_t s);
 void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_status, hipStream_t s);
 void launch_decode(const DecParams& p, hipStream_t s);
+void launch_crs_build_code(const uint64_t* d_hist, ghf_tree* d_tree, ghf_code* d_code, uint64_t* d_start_bit, int* d_status,
+                           hipStream_t s);
+void launch_crs_finish(const ghf_tree* d_tree, const uint64_t* d_total_bits, uint8_t* d_out, uint64_t* d_out_bytes, int* d_status,
+                       hipStream_t s);
+void launch_crs_decode_tables(const ghf_tree* d_tree, DecTables* d_dt, int* d_status, hipStream_t s);
 void launch_store_u64(uint64_t* d_dst, const uint64_t* d_src_opt, uint64_t add, hipStream_t s);
 void launch_shard_start(const ghf_code* d_code, const uint64_t* d_totals, int rank, uint64_t* d_start_bit, hipStream_t s);
 

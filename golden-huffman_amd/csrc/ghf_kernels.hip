@@ -523,6 +523,167 @@ void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// SURVEY 8(f) N3, the .crs format: EncodeHuffTree::build_tree + gen_encode + serialize_tree
+// (include/huff_tree.h:228-235, include/huff_tree.cc:138-187) on one wavefront.  The queue is the same
+// libstdc++ heap on the weight alone as K2's, so the same wave-parallel push/pop applies; what differs is
+// what is kept: the tree itself (left = first popped, right = second popped), because the codes are the
+// root-to-leaf paths and the file header is the tree in preorder.
+// ------------------------------------------------------------------------------------------------
+struct TreeLds {
+  uint16_t tl[256], tr[256];             // children of merge t (tree node ids of HeapLds: 0..255 leaves, 257 + t merges)
+  uint16_t size[GHF_NSYM + 256 + 7];     // nodes in the subtree
+  uint8_t is_right[GHF_NSYM + 256 + 7];  // the node is its parent's right child
+  uint32_t max_len, min_len;
+  int n;
+};
+
+__global__ __launch_bounds__(64) void k_crs_build_code(const unsigned long long* __restrict__ hist, ghf_tree* __restrict__ out_tree,
+                                                       ghf_code* __restrict__ out_code, unsigned long long* __restrict__ start_bit,
+                                                       int* __restrict__ status) {
+  __shared__ HeapLds heap;
+  __shared__ TreeLds T;
+  __shared__ ghf_tree tree;
+  const int lane = threadIdx.x;
+  for (int s = lane; s < GHF_NSYM; s += 64) heap.cur[s] = (uint16_t)s;
+  for (int i = lane; i < GHF_NSYM + 256 + 7; i += 64) {
+    heap.parent[i] = 0;
+    T.size[i] = 1;
+    T.is_right[i] = 0;
+  }
+  for (int i = lane; i < (int)(sizeof(ghf_tree) / 4); i += 64) reinterpret_cast<uint32_t*>(&tree)[i] = 0;
+  if (lane == 0) {
+    T.max_len = 0;
+    T.min_len = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  int n = 0;
+  for (int s = 0; s < 256; ++s) {  // huff_tree.h:228-235: keys ascending, zero counts skipped, no end mark
+    const u64t f = wave_uniform((u64t)hist[s]);
+    if (f) {
+      wave_heap_push(heap, n, (f << 9) | (u64t)s, lane);
+      ++n;
+    }
+  }
+  const int nleaves = n;
+  if (nleaves < 2) {
+    if (lane == 0) latch_status(status, nleaves == 0 ? GHF_E_EMPTY : GHF_E_SINGLE);
+    return;
+  }
+  const int times = n - 1;  // huff_tree.cc:141
+  for (int t = 0; t < times; ++t) {
+    const u64t e1 = wave_heap_pop(heap, n, lane);  // lchild, huff_tree.cc:143-144
+    const u64t e2 = wave_heap_pop(heap, n, lane);  // rchild, :145-146
+    const int s1 = (int)(e1 & 511u), s2 = (int)(e2 & 511u);
+    const int node = GHF_NSYM + t;
+    if (lane == 0) {
+      const int a = heap.cur[s1], b = heap.cur[s2];
+      heap.parent[a] = (uint16_t)node;
+      heap.parent[b] = (uint16_t)node;
+      T.tl[t] = (uint16_t)a;
+      T.tr[t] = (uint16_t)b;
+      T.is_right[b] = 1;
+      T.size[node] = (uint16_t)(1 + T.size[a] + T.size[b]);
+      heap.cur[s2] = (uint16_t)node;  // the parent travels through the heap under the second child's slot
+    }
+    wave_heap_push(heap, n, (((e1 >> 9) + (e2 >> 9)) << 9) | (u64t)s2, lane);  // :147-148, weight = sum (huff_tree.h:62-66)
+    ++n;
+  }
+  __syncthreads();
+  // every node walks up to the root: depth = code length, the turns taken = the code (root bit first), and
+  // 1 + (left sibling's subtree, when coming from the right) per step = its preorder position
+  for (int v = lane; v < GHF_NSYM + times; v += 64) {
+    const bool leaf = v < 256;
+    if (v == 256 || (leaf && heap.parent[v] == 0)) continue;  // the end-mark slot / absent symbols
+    uint32_t len = 0, pre = 0;
+    unsigned long long code = 0;
+    int x = v;
+    for (int p; (p = heap.parent[x]) != 0; x = p) {
+      const uint32_t r = T.is_right[x];
+      if (len < 64) code |= (unsigned long long)r << len;
+      ++len;
+      pre += 1u + (r ? (uint32_t)T.size[T.tl[p - GHF_NSYM]] : 0u);
+    }
+    if (leaf) {
+      tree.header[2 * pre] = 0;            // huff_tree.cc:178-181
+      tree.header[2 * pre + 1] = (uint8_t)v;
+      atomicMax(&T.max_len, len);
+      atomicMin(&T.min_len, len);
+      if (len <= 32) {
+        out_code->length[v] = len;
+        out_code->codeword[v] = (uint32_t)code;
+      }
+    } else {
+      tree.header[2 * pre] = 255;          // huff_tree.cc:183-184
+      tree.header[2 * pre + 1] = 255;
+      const int t = v - GHF_NSYM;
+      const int a = T.tl[t], b = T.tr[t];
+      tree.left[t] = (uint16_t)(a < GHF_NSYM ? a : 256 + (a - GHF_NSYM));
+      tree.right[t] = (uint16_t)(b < GHF_NSYM ? b : 256 + (b - GHF_NSYM));
+    }
+  }
+  // symbols that do not occur, the end-mark slot and the canonical-only tables of ghf_code
+  for (int s = lane; s < GHF_NSYM; s += 64) {
+    if (s == 256 || heap.parent[s] == 0) {
+      out_code->length[s] = 0;
+      out_code->codeword[s] = 0;
+    }
+    out_code->symbol[s] = 0xFFFFFFFFu;
+  }
+  for (int i = lane; i < 64; i += 64) {
+    out_code->first_code[i] = 0;
+    out_code->start_pos[i] = 0;
+  }
+  __syncthreads();
+  if (T.max_len > 32u) {  // K5 packs codes of at most 32 bits
+    if (lane == 0) latch_status(status, GHF_E_CODELEN);
+    return;
+  }
+  if (lane == 0) {
+    tree.root = (uint32_t)(256 + times - 1);
+    tree.n_leaves = (uint32_t)nleaves;
+    tree.max_len = T.max_len;
+    tree.tree_bytes = 2u * (2u * (uint32_t)nleaves - 1u);
+    out_code->min_len = (int32_t)T.min_len;
+    out_code->max_len = (int32_t)T.max_len;
+    if (start_bit) *start_bit = 8ull * ((unsigned long long)tree.tree_bytes + 2ull);  // normal_huff_encoder.h:163-164
+  }
+  __syncthreads();
+  for (int i = lane; i < (int)(sizeof(ghf_tree) / 4); i += 64)
+    reinterpret_cast<uint32_t*>(out_tree)[i] = reinterpret_cast<const uint32_t*>(&tree)[i];
+}
+
+void launch_crs_build_code(const uint64_t* d_hist, ghf_tree* d_tree, ghf_code* d_code, uint64_t* d_start_bit, int* d_status,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(k_crs_build_code, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(d_hist), d_tree,
+                     d_code, reinterpret_cast<unsigned long long*>(d_start_bit), d_status);
+}
+
+// The framing around the body (normal_huff_encoder.h:136-138,159-186): the tree, then {left_bits, last byte}.  K5 has
+// written the code bits from byte tree_bytes + 2 on, zero-filled to the end of their last byte; that byte is copied
+// into the prefix and no longer counted (the reference stores whole bytes only and seeks back for the rest).
+__global__ __launch_bounds__(256) void k_crs_finish(const ghf_tree* __restrict__ tree, const unsigned long long* __restrict__ total_bits,
+                                                    uint8_t* __restrict__ out, unsigned long long* __restrict__ out_bytes,
+                                                    const int* __restrict__ status) {
+  if (*status != 0) return;
+  const uint32_t tb = tree->tree_bytes;
+  for (uint32_t i = threadIdx.x; i < tb; i += 256) out[i] = tree->header[i];
+  if (threadIdx.x == 0) {
+    const unsigned long long t = *total_bits;
+    const unsigned long long whole = t >> 3;
+    const uint32_t left = (uint32_t)((8u - (uint32_t)(t & 7u)) & 7u);
+    out[tb] = (uint8_t)left;
+    out[tb + 1] = left ? out[tb + 2 + whole] : (uint8_t)0;
+    if (out_bytes) *out_bytes = (unsigned long long)tb + 2ull + whole;
+  }
+}
+
+void launch_crs_finish(const ghf_tree* d_tree, const uint64_t* d_total_bits, uint8_t* d_out, uint64_t* d_out_bytes, int* d_status,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(k_crs_finish, dim3(1), dim3(256), 0, s, d_tree, reinterpret_cast<const unsigned long long*>(d_total_bits), d_out,
+                     reinterpret_cast<unsigned long long*>(d_out_bytes), d_status);
+}
+
+// ------------------------------------------------------------------------------------------------
 // a5: header.  u32 big-endian: 257, symbol_[0..256], min_len, max_len, (start_pos[i], first_code[i]) i=1..max_len
 // (canonical_huff_encoder.cc:223-237, utils/include/buffer.h:261-268)
 // ------------------------------------------------------------------------------------------------
@@ -1087,6 +1248,8 @@ __global__ __launch_bounds__(256) void k_build_decode_tables(const ghf_code* __r
     dt->min_len = min_len;
     dt->max_len = max_len;
     dt->lut_bits = lb;
+    dt->kind = 0;
+    dt->root = 0;
   }
   if (tid < 16) dt->ticket[tid * 32] = 0;
   __syncthreads();
@@ -1130,6 +1293,64 @@ __global__ __launch_bounds__(256) void k_build_decode_tables(const ghf_code* __r
   }
 }
 
+// .crs: the same direct table, filled by walking the tree DecodeHuffTree::do_build_tree would rebuild
+// (include/huff_tree.cc:289-303); what the table cannot resolve is walked bit by bit like decode_byte does (:255-271).
+__global__ __launch_bounds__(256) void k_crs_decode_tables(const ghf_tree* __restrict__ tree, DecTables* __restrict__ dt,
+                                                           int* __restrict__ status) {
+  __shared__ uint16_t tl[256], tr[256];
+  __shared__ uint32_t s_min;
+  const int tid = threadIdx.x;
+  const int max_len = (int)tree->max_len;
+  const uint32_t root = tree->root, nl = tree->n_leaves;
+  if (max_len < 1 || max_len > 32 || nl < 2 || nl > 256 || root < 256 || root >= 256 + nl - 1) {
+    if (tid == 0) latch_status(status, GHF_E_FORMAT);
+    return;
+  }
+  tl[tid] = tree->left[tid];
+  tr[tid] = tree->right[tid];
+  if (tid == 0) s_min = 64;
+  __syncthreads();
+  const int lb = max_len < kDecLutBitsMax ? max_len : kDecLutBitsMax;
+  dt->tl[tid] = tl[tid];
+  dt->tr[tid] = tr[tid];
+  if (tid < 36) {
+    dt->fc_left[tid] = 0xFFFFFFFFu;
+    dt->start_pos[tid] = 0;
+  }
+  for (int i = tid; i < GHF_NSYM; i += 256) dt->symbol[i] = 256;
+  if (tid < 16) dt->ticket[tid * 32] = 0;
+  uint32_t mn = 64;
+  for (uint32_t idx = tid; idx < (1u << lb); idx += 256) {
+    uint32_t node = root;
+    uint16_t ent = 0;
+    for (int l = 1; l <= lb; ++l) {
+      const uint32_t p = node - 256u;
+      if (p >= nl - 1) break;  // a child id that is neither a leaf nor one of the nl - 1 parents: malformed, entry stays 0
+      node = ((idx >> (lb - l)) & 1u) ? tr[p] : tl[p];
+      if (node < 256u) {
+        ent = (uint16_t)(node | ((uint32_t)l << 9));
+        mn = (uint32_t)l < mn ? (uint32_t)l : mn;
+        break;
+      }
+    }
+    dt->lut[idx] = ent;
+  }
+  atomicMin(&s_min, mn);
+  __syncthreads();
+  if (tid == 0) {
+    dt->min_len = (int32_t)(s_min <= (uint32_t)lb ? s_min : (uint32_t)lb);
+    dt->max_len = max_len;
+    dt->lut_bits = lb;
+    dt->pair_bits = 0;
+    dt->kind = 1;
+    dt->root = root;
+  }
+}
+
+void launch_crs_decode_tables(const ghf_tree* d_tree, DecTables* d_dt, int* d_status, hipStream_t s) {
+  hipLaunchKernelGGL(k_crs_decode_tables, dim3(1), dim3(256), 0, s, d_tree, d_dt, d_status);
+}
+
 void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_status, hipStream_t s) {
   hipLaunchKernelGGL(k_build_decode_tables, dim3(1), dim3(256), 0, s, d_code, d_dt, d_status);
 }
@@ -1140,6 +1361,9 @@ struct DecLds {  // K6 (side-car reconstruction): 4 waves, plain table
   uint32_t fcl[36];
   uint32_t sp[36];
   uint16_t symbol[GHF_NSYM + 3];
+  uint16_t tl[256], tr[256];  // kind 1 (.crs): the tree
+  uint32_t root;
+  int kind;
   int status0;
 };
 
@@ -1160,6 +1384,9 @@ struct DecLds7 {
   uint32_t fcl[36];
   uint32_t sp[36];
   uint16_t symbol[GHF_NSYM + 3];
+  uint16_t tl[256], tr[256];  // kind 1 (.crs): the tree
+  uint32_t root;
+  int kind;
   int status0;
 };
 static_assert(sizeof(DecLds7) <= 160 * 1024, "one workgroup of 16 waves per CU");
@@ -1171,6 +1398,14 @@ __device__ __forceinline__ void dec_small_load(LT& L, const DecTables* dt, int t
     L.sp[tid] = dt->start_pos[tid];
   }
   for (int i = tid; i < GHF_NSYM; i += nthreads) L.symbol[i] = dt->symbol[i];
+  for (int i = tid; i < 256; i += nthreads) {
+    L.tl[i] = dt->tl[i];
+    L.tr[i] = dt->tr[i];
+  }
+  if (tid == 0) {
+    L.kind = dt->kind;
+    L.root = dt->root;
+  }
 }
 
 __device__ __forceinline__ void dec_lds_load(DecLds& L, const DecTables* dt, int tid, int nthreads) {
@@ -1205,6 +1440,16 @@ __device__ __forceinline__ void dec_lds_load7(DecLds7& L, const DecTables* dt, i
 // returns sym | len << 16
 template <typename LT>
 __device__ __forceinline__ uint32_t dec_long(const LT& L, uint32_t hi, int lut_bits, int max_len) {
+  if (L.kind == 1) {  // .crs: walk the tree from the root (huff_tree.cc:255-271); malformed trees end in "no symbol"
+    uint32_t node = L.root;
+    for (int l = 1; l <= max_len; ++l) {
+      const uint32_t p = node - 256u;
+      if (p >= 256u) break;
+      node = ((hi >> (32 - l)) & 1u) ? L.tr[p] : L.tl[p];
+      if (node < 256u) return node | ((uint32_t)l << 16);
+    }
+    return 256u | ((uint32_t)max_len << 16);
+  }
   int l = lut_bits + 1;
   while (l < max_len && hi < L.fcl[l]) ++l;
   const uint32_t k = L.sp[l] + ((hi - L.fcl[l]) >> (32 - l));
@@ -1699,7 +1944,7 @@ __global__ __launch_bounds__(kDecThreads) void k_sync_pass(SyncParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
   const uint64_t ngroups = (P.nsub + 63) >> 6;
-  const uint64_t body_bits = P.stream_bytes * 8 - P.body_bit0;
+  const uint64_t body_bits = P.end_bit - P.body_bit0;
   uint32_t* in = L.in[wave];
   for (uint64_t g = (uint64_t)blockIdx.x * kDecWaves + wave; g < ngroups; g += (uint64_t)gridDim.x * kDecWaves) {
     const uint64_t sub = g * 64 + lane;
@@ -1734,6 +1979,9 @@ __global__ __launch_bounds__(kDecThreads) void k_sync_pass(SyncParams P) {
         pos += len;
         ++count;
       }
+      // .crs has no end mark: "eof" then means "this cannot be right" -- a bit pattern that is no code, or a last
+      // code that runs past the end of the stream
+      if (P.no_eof && pos > limit) eof = true;
       P.cnt[sub] = count;
       P.eof[sub] = eof ? 1 : 0;
       P.used[sub] = (uint16_t)st;
@@ -1797,7 +2045,7 @@ __global__ __launch_bounds__(kDecThreads) void k_sync_index(SyncParams P, uint64
   const uint64_t base = stage_subs(P, g * 64, in, lane);
   wave_sync();
   if (!valid) return;
-  const uint64_t body_bits = P.stream_bytes * 8 - P.body_bit0;
+  const uint64_t body_bits = P.end_bit - P.body_bit0;
   const uint64_t sub_lo = (uint64_t)lane * kSubBits;
   const uint64_t limit = body_bits - g * 64 * kSubBits;
   uint64_t pos = sub_lo + P.start[sub];

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GHF_LIB") or os.path.join(_HERE, "lib", "libghf.so")  # GHF_LIB: experiment builds only
 
 STATUS = {0: "ok", 1: "invalid argument", 2: "HIP error / no device", 3: "empty input", 4: "code longer than 32 bits",
-          5: "output capacity too small", 6: "not a .crs2 header", 7: "corrupt stream", 8: "out of memory"}
+          5: "output capacity too small", 6: "not a .crs2 / .crs header", 7: "corrupt stream", 8: "out of memory",
+          9: "one distinct byte value (.crs)"}
 
 
 class GhfError(RuntimeError):
@@ -63,13 +64,42 @@ class Index(C.Structure):
     ]
 
 
+class Tree(C.Structure):
+    """ghf_tree == the reference's HuffTree for the .crs format (include/huff_tree.h:98-176): node ids 0..255 are
+    leaves (the key), 256 + i is the i-th parent, left[i] / right[i] its children."""
+
+    _fields_ = [
+        ("left", C.c_uint16 * 256),
+        ("right", C.c_uint16 * 256),
+        ("root", C.c_uint32),
+        ("n_leaves", C.c_uint32),
+        ("max_len", C.c_uint32),
+        ("tree_bytes", C.c_uint32),
+        ("header", C.c_uint8 * 1024),
+    ]
+
+    def code_strings(self):
+        """the 256 root-to-leaf paths as '0'/'1' strings ('' for absent keys) -- NormalHuffEncoder::encode_map_"""
+        out = [""] * 256
+        stack = [(self.root, "")]
+        while stack:
+            node, path = stack.pop()
+            if node < 256:
+                out[node] = path
+            else:
+                stack.append((self.right[node - 256], path + "1"))
+                stack.append((self.left[node - 256], path + "0"))
+        return out
+
+
 EXPORTS = [
     "ghf_ctx_create", "ghf_ctx_destroy", "ghf_ctx_set_stream", "ghf_sync", "ghf_status", "ghf_clear_status",
     "ghf_last_error", "ghf_status_string", "ghf_version", "ghf_device_alloc", "ghf_device_free", "ghf_host_alloc",
     "ghf_host_free", "ghf_copy_h2d", "ghf_copy_d2h", "ghf_memset_d", "ghf_histogram", "ghf_build_code",
     "ghf_write_header", "ghf_header_bytes", "ghf_encode_plan", "ghf_encode_emit", "ghf_compress", "ghf_compress_bound",
     "ghf_chunk_symbols", "ghf_index_alloc", "ghf_index_free", "ghf_parse_header", "ghf_decode", "ghf_decoded_size",
-    "ghf_shard_start_bit",
+    "ghf_shard_start_bit", "ghf_crs_build_code", "ghf_crs_compress", "ghf_crs_compress_bound", "ghf_crs_parse_header",
+    "ghf_crs_decode", "ghf_crs_decoded_size",
 ]
 
 _lib = None
@@ -126,6 +156,13 @@ def lib():
     L.ghf_decode.argtypes = [vp, vp, sz, vp, C.POINTER(Index), vp, sz, vp]
     L.ghf_decoded_size.argtypes = [vp, vp, sz, vp, C.POINTER(u64)]
     L.ghf_shard_start_bit.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.ghf_crs_build_code.argtypes = [vp, vp, vp, vp]
+    L.ghf_crs_compress.argtypes = [vp, vp, sz, vp, sz, vp, vp, C.POINTER(Index)]
+    L.ghf_crs_compress_bound.argtypes = [sz]
+    L.ghf_crs_compress_bound.restype = sz
+    L.ghf_crs_parse_header.argtypes = [vp, sz, C.POINTER(Tree), C.POINTER(sz)]
+    L.ghf_crs_decode.argtypes = [vp, vp, sz, i32, vp, C.POINTER(Index), vp, sz, vp]
+    L.ghf_crs_decoded_size.argtypes = [vp, vp, sz, i32, vp, C.POINTER(u64)]
     _lib = L
     return L
 
@@ -149,6 +186,19 @@ def parse_header(host_bytes):
     if rc:
         raise GhfError(rc, "ghf_parse_header")
     return code, hs.value
+
+
+def crs_parse_header(host_bytes):
+    """host-side parse + validation of a .crs tree header (reference include/huff_tree.cc:289-303). -> (Tree, tree_bytes)"""
+    import numpy as np
+
+    a = np.ascontiguousarray(host_bytes, dtype=np.uint8)
+    tree = Tree()
+    tb = C.c_size_t(0)
+    rc = lib().ghf_crs_parse_header(a.ctypes.data, a.size, C.byref(tree), C.byref(tb))
+    if rc:
+        raise GhfError(rc, "ghf_crs_parse_header")
+    return tree, tb.value
 
 
 class Context:
@@ -291,4 +341,54 @@ class Context:
             self.L.ghf_decode(self.h, d_stream.data_ptr(), stream_bytes, d_code.data_ptr(),
                               None if index is None else C.byref(index), d_out.data_ptr(), d_out.numel(), nbytes.data_ptr()),
             "ghf_decode")
+        return d_out, nbytes
+
+    # ---- .crs (NormalHuffEncoder / NormalHuffDecoder) ---------------------------
+    def new_tree(self):
+        return self.torch.zeros(C.sizeof(Tree), dtype=self.torch.uint8, device=self.device)
+
+    def tree_to_host(self, d_tree):
+        return Tree.from_buffer_copy(d_tree.cpu().numpy().tobytes())
+
+    def tree_to_device(self, tree):
+        import numpy as np
+
+        return self.torch.from_numpy(np.frombuffer(bytes(tree), dtype=np.uint8).copy()).to(self.device)
+
+    def crs_build_code(self, d_hist, d_tree=None, d_code=None):
+        d_tree = self.new_tree() if d_tree is None else d_tree
+        d_code = self.new_code() if d_code is None else d_code
+        self._chk(self.L.ghf_crs_build_code(self.h, d_hist.data_ptr(), d_tree.data_ptr(), d_code.data_ptr()), "ghf_crs_build_code")
+        return d_tree, d_code
+
+    def crs_compress(self, d_in, d_out=None, d_tree=None, index=None, n=None):
+        """-> (d_out, d_out_bytes[1] int64 device, d_tree)"""
+        n = d_in.numel() if n is None else n
+        if d_out is None:
+            d_out = self.empty_u8(int(self.L.ghf_crs_compress_bound(n)))
+        if d_tree is None:
+            d_tree = self.new_tree()
+        nbytes = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
+        self._chk(
+            self.L.ghf_crs_compress(self.h, d_in.data_ptr(), n, d_out.data_ptr(), d_out.numel(), nbytes.data_ptr(),
+                                    d_tree.data_ptr(), None if index is None else C.byref(index)),
+            "ghf_crs_compress")
+        return d_out, nbytes, d_tree
+
+    def crs_decoded_size(self, d_stream, stream_bytes, left_bits, d_tree):
+        n = C.c_uint64(0)
+        self._chk(self.L.ghf_crs_decoded_size(self.h, d_stream.data_ptr(), stream_bytes, left_bits, d_tree.data_ptr(), C.byref(n)),
+                  "ghf_crs_decoded_size")
+        return n.value
+
+    def crs_decode(self, d_stream, stream_bytes, left_bits, d_tree, index=None, d_out=None, cap=None, nbytes=None):
+        """d_stream: the .crs image with the stored last byte appended behind the body when left_bits != 0."""
+        if d_out is None:
+            d_out = self.empty_u8(index.n_symbols if index is not None else cap)
+        if nbytes is None:
+            nbytes = self.torch.empty(1, dtype=self.torch.int64, device=self.device)
+        self._chk(
+            self.L.ghf_crs_decode(self.h, d_stream.data_ptr(), stream_bytes, left_bits, d_tree.data_ptr(),
+                                  None if index is None else C.byref(index), d_out.data_ptr(), d_out.numel(), nbytes.data_ptr()),
+            "ghf_crs_decode")
         return d_out, nbytes

@@ -32,7 +32,9 @@ enum ghf_status_code {
   GHF_E_CAP = 5,     /* output capacity too small */
   GHF_E_FORMAT = 6,  /* not a .crs2 header */
   GHF_E_CORRUPT = 7, /* stream does not decode to the expected symbol count / end mark */
-  GHF_E_NOMEM = 8
+  GHF_E_NOMEM = 8,
+  GHF_E_SINGLE = 9 /* .crs only: one distinct byte value -- the lone leaf gets the empty code and the reference's
+                      decoder dereferences a NULL child (include/huff_tree.cc:255-271); undefined there, refused here */
 };
 
 /* The encoder's tables -- mirrors the private members of CanonicalHuffEncoder,
@@ -168,6 +170,55 @@ int ghf_decode(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, const
  * side-car on the GPU, synchronises, and keeps it for a following ghf_decode(index = NULL) of the same
  * (d_stream, stream_bytes), which then does not repeat the work. */
 int ghf_decoded_size(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code, uint64_t* n_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * the `.crs` format -- Compressor<NormalHuffEncoder<>> / Decompressor<NormalHuffDecoder<>>
+ * (include/normal_huff_encoder.h, include/huff_tree.h, include/huff_tree.cc).  Same histogram (256 byte values,
+ * no end mark), the Huffman TREE itself defines the codes ('0' = left = first popped, '1' = right), the file is
+ *   [tree in preorder, 2 bytes per node: (0, key) leaf / (255, 255) parent] [left_bits] [last byte] [whole body bytes]
+ * The kernels are the ones above (K1, K4, K5, K7, K6); only the code assignment and the framing differ.
+ * Codes longer than 32 bits are refused (GHF_E_CODELEN) although the reference, which keeps them as strings, could
+ * write them: they need > 3.5 M input bytes arranged like Fibonacci numbers.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* The tree as NormalHuffEncoder builds it (EncodeHuffTree, include/huff_tree.h:175-262) and NormalHuffDecoder
+ * rebuilds it (DecodeHuffTree::do_build_tree, include/huff_tree.cc:289-303).  Node ids: 0..255 = leaf with that
+ * key, 256 + i = the i-th parent; left[i] / right[i] are the children of parent i. */
+typedef struct ghf_tree {
+  uint16_t left[256];
+  uint16_t right[256];
+  uint32_t root;        /* node id; >= 256 (a tree that is a single leaf is refused) */
+  uint32_t n_leaves;    /* 2 .. 256 */
+  uint32_t max_len;     /* depth of the deepest leaf, <= 32 */
+  uint32_t tree_bytes;  /* 2 * (2 * n_leaves - 1) */
+  uint8_t header[1024]; /* the preorder serialisation (tree_bytes of it), huff_tree.cc:174-187 */
+} ghf_tree;
+
+/* EncodeHuffTree::build_tree + gen_encode + serialize_tree (include/huff_tree.cc:138-187) on one wavefront.
+ * d_hist: ghf_histogram()'s output (slot [256] is ignored).  d_code receives length[] / codeword[] for K4/K5. */
+int ghf_crs_build_code(ghf_ctx* ctx, const uint64_t* d_hist, ghf_tree* d_tree, ghf_code* d_code);
+
+/* Compressor<NormalHuffEncoder<>>::compress() (include/compressor.h:62-73, normal_huff_encoder.h:136-186).
+ * d_out_bytes <- size of the .crs image.  If the body ends inside a byte, that byte (zero-filled) is ALSO left in
+ * d_out right behind the image, which is the layout ghf_crs_decode() wants.  d_tree (optional) receives the tree. */
+int ghf_crs_compress(ghf_ctx* ctx, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes,
+                     ghf_tree* d_tree, const ghf_index* index);
+size_t ghf_crs_compress_bound(size_t n);
+
+/* DecodeHuffTree::build_tree (include/huff_tree.cc:289-303) on the host, with the checks the reference lacks
+ * (truncated / over-long / degenerate trees -> GHF_E_FORMAT, depth > 32 -> GHF_E_CODELEN).  *tree_bytes <- size of
+ * the serialised tree; the two prefix bytes {left_bits, last byte} follow it (normal_huff_encoder.h:163-164). */
+int ghf_crs_parse_header(const uint8_t* h_stream, size_t n, ghf_tree* tree, size_t* tree_bytes);
+
+/* Decompressor<NormalHuffDecoder<>>::decompress() (include/huff_tree.cc:191-207,255-271).
+ * d_stream / stream_bytes: the .crs image from its first byte, with -- when left_bits != 0 -- the stored last byte
+ * appended behind the body (so that the code bits are contiguous); stream_bytes counts that byte.
+ * index == NULL: the side-car is rebuilt on the GPU (K6) and the stream must end exactly on a code boundary,
+ * left_bits bits before its last byte ends. */
+int ghf_crs_decode(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, int left_bits, const ghf_tree* d_tree,
+                   const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes);
+int ghf_crs_decoded_size(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, int left_bits, const ghf_tree* d_tree,
+                         uint64_t* n_out);
 
 #ifdef __cplusplus
 }

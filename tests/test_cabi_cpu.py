@@ -82,3 +82,42 @@ def test_parse_header_rejects_garbage(ghf, golden):
             ghf.parse_header(bad)
     with pytest.raises(ghf.GhfError):
         ghf.parse_header(hdr[:500])
+
+
+# ---------------------------------------------------------------- .crs host-side entry points
+def test_crs_struct_layout(ghf):
+    assert C.sizeof(ghf.Tree) == 2 * 256 * 2 + 4 * 4 + 1024
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_crs_parse_header_against_reference_trees(ghf, golden_crs, name):
+    g = golden_crs[name]
+    if "undefined" in g:
+        return
+    hdr = np.frombuffer(base64.b64decode(g["tree_b64"]), dtype=np.uint8)
+    tree, tb = ghf.crs_parse_header(np.concatenate([hdr, np.zeros(2, np.uint8)]))
+    assert tb == g["tree_bytes"] == tree.tree_bytes
+    assert tree.code_strings() == g["codes"]
+    assert tree.max_len == g["max_len"] and tree.n_leaves == sum(1 for c in g["codes"] if c)
+    assert bytes(tree.header[:tb]) == bytes(hdr)
+
+
+def test_crs_parse_header_rejects_garbage(ghf, golden_crs):
+    hdr = np.frombuffer(base64.b64decode(golden_crs["zipf_64k"]["tree_b64"]), dtype=np.uint8)
+    with pytest.raises(ghf.GhfError) as e:
+        ghf.crs_parse_header(hdr[:-2])  # truncated: the last leaf is missing
+    assert e.value.status == 6
+    with pytest.raises(ghf.GhfError) as e:
+        ghf.crs_parse_header(np.array([0, 65], dtype=np.uint8))  # the root is a leaf
+    assert e.value.status == 6
+    with pytest.raises(ghf.GhfError) as e:
+        ghf.crs_parse_header(np.full(2000, 255, dtype=np.uint8))  # parents only, never closes
+    assert e.value.status == 6
+    # a 40-deep comb: well-formed, but deeper than the 32-bit codes the kernels handle
+    comb = []
+    for d in range(40):
+        comb += [255, 255, 0, d]
+    comb += [0, 200]
+    with pytest.raises(ghf.GhfError) as e:
+        ghf.crs_parse_header(np.array(comb, dtype=np.uint8))
+    assert e.value.status == 4
