@@ -4,6 +4,9 @@
 //                             canonical_huff_char.{compress_perf,decomress_perf,func},
 //                             fast_canonical_huff_char.{decomress_perf,func}, table_canonical_huff_char.{...}
 //                             (compress once, decompress with the three decoder names, byte-compare each time)
+//                             and normal_huff_char.{compress_perf,decomress_perf,func} (:165-210, commented out there)
+//   ghf_tool <file> 1         compress   <file> -> <file>.crs   (normal Huffman, unit_tests/test.cc:295-297)
+//   ghf_tool <file> 2         decompress <file> -> <file>.de    (normal Huffman, :299-301)
 //   ghf_tool <file> 3         compress   <file> -> <file>.crs2                 (unit_tests/test.cc:302-304)
 //   ghf_tool <file> 4|5|6     decompress <file> -> <file>.de   (canonical | fast | table decoder, :306-314)
 // Exit code 0 = everything matched.
@@ -20,6 +23,7 @@ using namespace glzip_hip;
 
 static std::string infile_name("5big.log");  // the reference's default, unit_tests/test.cc:38
 static std::string outfile_name, infile_name2, outfile_name2;
+static Compressor<HipNormalHuffEncoder<> > compressor;       // file-scope like unit_tests/test.cc:45
 static Compressor<HipCanonicalHuffEncoder<> > compressor2;  // file-scope like unit_tests/test.cc:46
 
 static double now_ms() {
@@ -59,6 +63,12 @@ static bool compressor_func_test() {
   return ok;
 }
 
+static void normal_huff_char_compress(const std::string& in) {  // unit_tests/test.cc:116-121
+  outfile_name.clear();
+  compressor.set_file(in, outfile_name);
+  compressor.compress();
+  compressor.clear();
+}
 static void canonical_huff_char_compress(const std::string& in) {  // unit_tests/test.cc:129-134
   outfile_name.clear();
   compressor2.set_file(in, outfile_name);
@@ -92,12 +102,14 @@ int main(int argc, char* argv[]) {
   try {
     if (argc == 3) {
       const int type = atoi(argv[2]);
-      if (type == 3) canonical_huff_char_compress(infile_name);
+      if (type == 1) normal_huff_char_compress(infile_name);
+      else if (type == 2) decompress_with<HipNormalHuffDecoder<> >(infile_name);
+      else if (type == 3) canonical_huff_char_compress(infile_name);
       else if (type == 4) decompress_with<HipCanonicalHuffDecoder<> >(infile_name);
       else if (type == 5) decompress_with<HipFastCanonicalHuffDecoder<> >(infile_name);
       else if (type == 6) decompress_with<HipTableCanonicalHuffDecoder<> >(infile_name);
       else {
-        fprintf(stderr, "modes 1/2 (normal Huffman, .crs) are out of scope; use 3..6\n");
+        fprintf(stderr, "mode must be 1..6\n");
         return 2;
       }
       return 0;
@@ -114,6 +126,10 @@ int main(int argc, char* argv[]) {
   failed += !run("fast_canonical_huff_char.func", compressor_func_test);
   failed += !run("table_canonical_huff_char.decomress_perf", [] { decompress_with<HipTableCanonicalHuffDecoder<> >(outfile_name); return true; });
   failed += !run("table_canonical_huff_char.func", compressor_func_test);
-  printf("[==========] 7 tests ran, %d failed. compressed file: %s\n", failed, outfile_name.c_str());
+  const std::string crs2 = outfile_name;
+  failed += !run("normal_huff_char.compress_perf", [] { normal_huff_char_compress(infile_name); return true; });
+  failed += !run("normal_huff_char.decomress_perf", [] { decompress_with<HipNormalHuffDecoder<> >(outfile_name); return true; });
+  failed += !run("normal_huff_char.func", compressor_func_test);
+  printf("[==========] 10 tests ran, %d failed. compressed files: %s %s\n", failed, crs2.c_str(), outfile_name.c_str());
   return failed ? 1 : 0;
 }

@@ -379,5 +379,182 @@ class HipTableCanonicalHuffDecoder : public HipCanonicalHuffDecoder<_KeyType> {
   HipTableCanonicalHuffDecoder(const std::string& in, std::string& out) : HipCanonicalHuffDecoder<_KeyType>(in, out) {}
 };
 
+// ================================================================================================
+// the .crs format.  Same member functions, same order (Compressor<>::compress() and
+// Decompressor<>::decompress() above do not change): drop-ins for NormalHuffEncoder<> / NormalHuffDecoder<>
+// (include/normal_huff_encoder.h:57-283).
+// ================================================================================================
+template <typename _KeyType = unsigned char>
+class HipNormalHuffEncoder;
+
+template <>
+class HipNormalHuffEncoder<unsigned char> {
+ public:
+  HipNormalHuffEncoder(const std::string& infile_name, std::string& outfile_name) : infile_(NULL), outfile_(NULL), n_(0) {
+    set_file(infile_name, outfile_name);
+  }
+  HipNormalHuffEncoder() : infile_(NULL), outfile_(NULL), n_(0) {}
+  ~HipNormalHuffEncoder() { clear(); }
+
+  // include/normal_huff_encoder.h:83-99: the output name defaults to <in>.crs and is handed back
+  void set_file(const std::string& infile_name, std::string& outfile_name) {
+    clear();
+    infile_name_ = infile_name;
+    infile_ = fopen(infile_name.c_str(), "rb");
+    if (!infile_) throw Error(GHF_E_INVAL, "cannot open input file " + infile_name);
+    if (outfile_name.empty()) outfile_name = infile_name + ".crs";
+    outfile_ = fopen(outfile_name.c_str(), "wb");
+    if (!outfile_) throw Error(GHF_E_INVAL, "cannot open output file " + outfile_name);
+  }
+
+  void clear() {  // include/encoder.h:85-92
+    if (infile_) fclose(infile_);
+    if (outfile_) fclose(outfile_);
+    infile_ = NULL;
+    outfile_ = NULL;
+  }
+
+  // include/encoder.h:99-105,136-150 (no end-mark slot in this format: init_nhuff, normal_huff_encoder.h:189-196)
+  void caculate_frequency() {
+    n_ = detail::file_size(infile_);
+    if (n_ == 0) throw Error(GHF_E_EMPTY, "empty input: undefined in the reference, refused here");
+    d_in_.alloc(s_, n_ + 16);
+    d_hist_.alloc(s_, GHF_NSYM * sizeof(uint64_t));
+    stager_.to_device(infile_, d_in_.u8(), n_, infile_name_);
+    s_.check(ghf_histogram(s_.ctx(), d_in_.u8(), n_, static_cast<uint64_t*>(d_hist_.p)), "ghf_histogram");
+  }
+
+  // include/normal_huff_encoder.h:110-121 -> EncodeHuffTree::build_tree + gen_encode (include/huff_tree.cc:138-171)
+  void gen_encode() {
+    d_tree_.alloc(s_, sizeof(ghf_tree));
+    d_code_.alloc(s_, sizeof(ghf_code));
+    s_.check(ghf_crs_build_code(s_.ctx(), static_cast<const uint64_t*>(d_hist_.p), static_cast<ghf_tree*>(d_tree_.p),
+                                static_cast<ghf_code*>(d_code_.p)),
+             "ghf_crs_build_code");
+    s_.check(ghf_copy_d2h(s_.ctx(), &tree_, d_tree_.p, sizeof(ghf_tree)), "ghf_copy_d2h");
+    s_.sync("gen_encode");
+  }
+
+  // include/normal_huff_encoder.h:136-138 -> serialize_tree (include/huff_tree.cc:174-187): the tree at file offset 0
+  void write_encode_info() {
+    fseek(outfile_, 0, SEEK_SET);
+    if (fwrite(tree_.header, 1, tree_.tree_bytes, outfile_) != tree_.tree_bytes) throw Error(GHF_E_INVAL, "short write (tree)");
+    fflush(outfile_);
+  }
+
+  // include/normal_huff_encoder.h:159-186: {left_bits, last byte}, then the whole bytes of the body
+  void encode_file() {
+    const size_t hdr = (size_t)tree_.tree_bytes + 2;
+    cap_ = ghf_crs_compress_bound(n_);
+    d_out_.alloc(s_, cap_);
+    detail::DeviceBuf d_scal;
+    d_scal.alloc(s_, 4 * sizeof(uint64_t));  // [0] start bit, [1] total bits, [2..3] end
+    uint64_t* ds = static_cast<uint64_t*>(d_scal.p);
+    const uint64_t start_bit = 8ull * hdr;
+    uint64_t scal[4] = {start_bit, 0, 0, 0};
+    const ghf_code* dc = static_cast<const ghf_code*>(d_code_.p);
+    s_.check(ghf_copy_h2d(s_.ctx(), ds, scal, sizeof(uint64_t)), "ghf_copy_h2d");
+    s_.check(ghf_encode_plan(s_.ctx(), d_in_.u8(), n_, dc, ds + 1), "ghf_encode_plan");
+    s_.check(ghf_encode_emit(s_.ctx(), d_in_.u8(), n_, dc, ds, 0, d_out_.u8(), cap_, NULL, ds + 2), "ghf_encode_emit");
+    s_.check(ghf_copy_d2h(s_.ctx(), scal, ds, sizeof scal), "ghf_copy_d2h");
+    s_.sync("encode_file");
+    const uint64_t bits = scal[1];
+    const size_t whole = (size_t)(bits >> 3);
+    const unsigned left = (unsigned)((8 - (bits & 7)) & 7);
+    unsigned char prefix[2] = {(unsigned char)left, 0};
+    if (left) {  // the zero-filled last byte sits right behind the whole bytes (the emit kernels zero-fill their last unit)
+      s_.check(ghf_copy_d2h(s_.ctx(), prefix + 1, d_out_.u8() + hdr + whole, 1), "ghf_copy_d2h");
+      s_.sync("encode_file (last byte)");
+    }
+    if (fwrite(prefix, 1, 2, outfile_) != 2) throw Error(GHF_E_INVAL, "short write (prefix)");
+    stager_.to_file(d_out_.u8() + hdr, whole, outfile_, "output (body)");
+    fflush(outfile_);
+  }
+
+  const ghf_tree& tree() const { return tree_; }
+
+ private:
+  HipNormalHuffEncoder(const HipNormalHuffEncoder&);
+  HipNormalHuffEncoder& operator=(const HipNormalHuffEncoder&);
+  detail::Session s_;
+  FILE* infile_;
+  FILE* outfile_;
+  std::string infile_name_;
+  size_t n_, cap_;
+  detail::DeviceBuf d_in_, d_hist_, d_tree_, d_code_, d_out_;
+  detail::Stager stager_;
+  ghf_tree tree_;
+};
+
+template <typename _KeyType = unsigned char>
+class HipNormalHuffDecoder;
+
+template <>
+class HipNormalHuffDecoder<unsigned char> {
+ public:
+  // include/encoder.h:227-232: the output name defaults to <in>.de and is handed back
+  HipNormalHuffDecoder(const std::string& infile_name, std::string& outfile_name) : n_(0), tb_(0), left_(0), last_(0) {
+    infile_ = fopen(infile_name.c_str(), "rb");
+    if (!infile_) throw Error(GHF_E_INVAL, "cannot open input file " + infile_name);
+    if (outfile_name.empty()) outfile_name = infile_name + ".de";
+    outfile_ = fopen(outfile_name.c_str(), "wb");
+    if (!outfile_) {
+      fclose(infile_);
+      throw Error(GHF_E_INVAL, "cannot open output file " + outfile_name);
+    }
+  }
+  ~HipNormalHuffDecoder() {
+    if (infile_) fclose(infile_);
+    if (outfile_) fclose(outfile_);
+  }
+
+  // include/normal_huff_encoder.h:268-271 -> DecodeHuffTree::build_tree (include/huff_tree.cc:289-303), validated
+  void get_encode_info() {
+    n_ = detail::file_size(infile_);
+    std::vector<uint8_t> head(n_ < 1024 ? n_ : 1024);  // the largest tree: 2 * 511 bytes, then the two prefix bytes
+    if (fread(head.data(), 1, head.size(), infile_) != head.size()) throw Error(GHF_E_INVAL, "short read");
+    s_.check(ghf_crs_parse_header(head.data(), head.size(), &tree_, &tb_), "ghf_crs_parse_header");
+    if (tb_ + 2 > head.size()) throw Error(GHF_E_FORMAT, "the two bytes behind the tree are missing");
+    left_ = head[tb_];       // include/huff_tree.cc:195-196
+    last_ = head[tb_ + 1];
+    if (left_ > 7) throw Error(GHF_E_FORMAT, "left_bits > 7");
+    fseek(infile_, 0, SEEK_SET);
+  }
+
+  // include/normal_huff_encoder.h:272-274 -> DecodeHuffTree::decode_file (include/huff_tree.cc:191-207)
+  void decode_file() {
+    d_in_.alloc(s_, n_ + 32);
+    d_tree_.alloc(s_, sizeof(ghf_tree));
+    stager_.to_device(infile_, d_in_.u8(), n_, "input");
+    size_t stream_bytes = n_;
+    if (left_) {  // the stored last byte goes behind the body, where its bits belong
+      s_.check(ghf_copy_h2d(s_.ctx(), d_in_.u8() + n_, &last_, 1), "ghf_copy_h2d");
+      ++stream_bytes;
+    }
+    s_.check(ghf_copy_h2d(s_.ctx(), d_tree_.p, &tree_, sizeof(ghf_tree)), "ghf_copy_h2d");
+    const ghf_tree* dt = static_cast<const ghf_tree*>(d_tree_.p);
+    uint64_t n_out = 0;
+    s_.check(ghf_crs_decoded_size(s_.ctx(), d_in_.u8(), stream_bytes, (int)left_, dt, &n_out), "ghf_crs_decoded_size");
+    d_out_.alloc(s_, (size_t)n_out + 16);
+    s_.check(ghf_crs_decode(s_.ctx(), d_in_.u8(), stream_bytes, (int)left_, dt, NULL, d_out_.u8(), (size_t)n_out + 16, NULL),
+             "ghf_crs_decode");
+    s_.sync("decode_file");
+    stager_.to_file(d_out_.u8(), (size_t)n_out, outfile_, "output");
+    fflush(outfile_);
+  }
+
+ private:
+  HipNormalHuffDecoder(const HipNormalHuffDecoder&);
+  HipNormalHuffDecoder& operator=(const HipNormalHuffDecoder&);
+  detail::Session s_;
+  FILE* infile_;
+  FILE* outfile_;
+  size_t n_, tb_;
+  uint8_t left_, last_;
+  detail::DeviceBuf d_in_, d_tree_, d_out_;
+  detail::Stager stager_;
+  ghf_tree tree_;
+};
+
 }  // namespace glzip_hip
 #endif  // GLZIP_HIP_H_

@@ -19,6 +19,9 @@ DRIVER = textwrap.dedent(
     using glzip_hip::HipCanonicalHuffDecoder;
     using glzip_hip::HipFastCanonicalHuffDecoder;
     using glzip_hip::HipTableCanonicalHuffDecoder;
+    using glzip_hip::HipNormalHuffEncoder;
+    using glzip_hip::HipNormalHuffDecoder;
+    glzip::Compressor<HipNormalHuffEncoder<> > compressor;       // test.cc:45
     glzip::Compressor<HipCanonicalHuffEncoder<> > compressor2;   // by-value member + default ctor, like test.cc:46
     int main(int argc, char** argv) {
       if (argc < 2) return 0;                                     // link check only; running needs a GPU
@@ -32,6 +35,11 @@ DRIVER = textwrap.dedent(
       out2.clear();
       { glzip::Decompressor<HipTableCanonicalHuffDecoder<> > d(out, out2); d.decompress(); }
       glzip::Compressor<HipCanonicalHuffEncoder<> > c2(in, out);  // the two-argument ctor, compressor.h:47-48
+      out.clear(); out2.clear();
+      compressor.set_file(in, out);                               // .crs, test.cc:116-121
+      compressor.compress();
+      compressor.clear();
+      { glzip::Decompressor<HipNormalHuffDecoder<> > d(out, out2); d.decompress(); }
       return 0;
     }
     """

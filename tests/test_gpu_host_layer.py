@@ -27,17 +27,21 @@ def tool():
     return TOOL
 
 
-def test_config1_suite_like_unit_tests_test_cc(tool, tmp_path, golden):
+def test_config1_suite_like_unit_tests_test_cc(tool, tmp_path, golden, golden_crs):
     data = CASES["text_1m"]()
     f = tmp_path / "text_1m.bin"
     data.tofile(f)
     r = subprocess.run([tool, str(f)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "7 tests ran, 0 failed" in r.stdout
+    assert "10 tests ran, 0 failed" in r.stdout
     crs = np.fromfile(str(f) + ".crs2", dtype=np.uint8)  # default name: <in>.crs2 (canonical_huff_encoder.cc:19-22)
     assert sha(crs) == golden["text_1m"]["crs2_sha256"]
     de = np.fromfile(str(f) + ".crs2.de", dtype=np.uint8)  # default name: <in>.de (encoder.h:229-230)
     assert np.array_equal(de, data)
+    # the normal-Huffman leg of the suite: <in>.crs (normal_huff_encoder.h:84-88) and <in>.crs.de
+    crs1 = np.fromfile(str(f) + ".crs", dtype=np.uint8)
+    assert sha(crs1) == golden_crs["text_1m"]["crs_sha256"]
+    assert np.array_equal(np.fromfile(str(f) + ".crs.de", dtype=np.uint8), data)
 
 
 @pytest.mark.parametrize("name", ["aaaabbc", "single_x", "all256_once", "zipf_64k", "fib32_maxlen32", "uniform_65537"])
@@ -88,3 +92,44 @@ def test_streaming_stager_multi_piece_file(tool, tmp_path):
     assert crs.size == ref.size and sha(crs) == sha(ref)
     assert subprocess.run([tool, str(f) + ".crs2", "6"], timeout=300).returncode == 0
     assert np.array_equal(np.fromfile(str(f) + ".crs2.de", dtype=np.uint8), data)
+
+
+@pytest.mark.parametrize("name", ["aaaabbc", "ab", "all256_once", "zipf_64k", "fib32_maxlen32", "uniform_65537", "sym16_n1003"])
+def test_crs_mode_switch_compress_then_decompress(tool, tmp_path, golden_crs, name):
+    """modes 1 / 2 of unit_tests/test.cc:295-301: Compressor<NormalHuffEncoder<>> / Decompressor<NormalHuffDecoder<>>"""
+    data = CASES[name]()
+    f = tmp_path / (name + ".bin")
+    data.tofile(f)
+    assert subprocess.run([tool, str(f), "1"], timeout=120).returncode == 0
+    crs = np.fromfile(str(f) + ".crs", dtype=np.uint8)
+    assert crs.size == golden_crs[name]["crs_bytes"] and sha(crs) == golden_crs[name]["crs_sha256"]
+    assert subprocess.run([tool, str(f) + ".crs", "2"], timeout=120).returncode == 0
+    assert np.array_equal(np.fromfile(str(f) + ".crs.de", dtype=np.uint8), data)
+
+
+def test_crs_interop_with_the_reference_algorithm(tool, tmp_path):
+    """a .crs written by the reference's algorithm (the oracle; with the compiled reference itself when it is around)
+    is decoded by ghf_tool, and what ghf_tool writes is decoded by them"""
+    data = CASES["text_131073"]()
+    f = tmp_path / "ref.crs"
+    orc.crs_compress(data).tofile(f)
+    assert subprocess.run([tool, str(f), "2"], timeout=120).returncode == 0
+    assert np.array_equal(np.fromfile(str(f) + ".de", dtype=np.uint8), data)
+    g = tmp_path / "mine.bin"
+    data.tofile(g)
+    assert subprocess.run([tool, str(g), "1"], timeout=120).returncode == 0
+    mine = np.fromfile(str(g) + ".crs", dtype=np.uint8)
+    assert np.array_equal(orc.crs_decompress(mine), data)
+    if orc.have_ref():
+        orc.ref_run(["nd", str(g) + ".crs", str(tmp_path / "ref.de")])
+        assert np.array_equal(np.fromfile(tmp_path / "ref.de", dtype=np.uint8), data)
+
+
+def test_crs_errors_are_reported_not_undefined(tool, tmp_path):
+    one = tmp_path / "one.bin"
+    one.write_bytes(b"x" * 1000)  # a single distinct byte: NULL dereference in the reference's decoder, status 9 here
+    r = subprocess.run([tool, str(one), "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "error 9" in r.stderr
+    junk = tmp_path / "junk.crs"
+    junk.write_bytes(b"\xff" * 4000)
+    assert subprocess.run([tool, str(junk), "2"], capture_output=True, timeout=60).returncode == 1
