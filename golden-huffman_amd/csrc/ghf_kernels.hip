@@ -1489,6 +1489,7 @@ __device__ __forceinline__ uint32_t decode_segment(const LT& L, const DecIn<STAG
                                                    const uint16_t* lut1, int pair_bits, uint32_t rep2, uint32_t* outl,
                                                    uint32_t osw) {
   const int lsh = 32 - lut_bits;
+  const char* lut1b = reinterpret_cast<const char*>(lut1 + rep);  // this lane's replica: address = base + (index << (rshift + 1))
   uint32_t widx = (uint32_t)(pos >> 5);
   uint32_t o = (uint32_t)(pos & 31u);
   const uint32_t o0 = o, widx0 = widx;
@@ -1515,7 +1516,7 @@ __device__ __forceinline__ uint32_t decode_segment(const LT& L, const DecIn<STAG
 #define GHF_DEC(ENT)                                          \
   do {                                                        \
     const uint32_t v_ = (uint32_t)((W << o) >> 32);           \
-    ENT = GHF_EXP_LUT(lut1[((v_ >> lsh) << rshift) | rep], v_); \
+    ENT = GHF_EXP_LUT(*reinterpret_cast<const uint16_t*>(lut1b + ((v_ >> lsh) << (rshift + 1))), v_); \
     if (LONG && __builtin_expect((ENT >> 9) == 0, 0)) {       \
       const uint32_t r_ = dec_long(L, v_, lut_bits, max_len); \
       ENT = (r_ & 0x1FFu) | ((r_ >> 16) << 9);                \
@@ -1528,6 +1529,7 @@ __device__ __forceinline__ uint32_t decode_segment(const LT& L, const DecIn<STAG
     // shift -> lookup -> add chain is half as long.  Two pairs (<= 2 * pair_bits <= 24 bits) per refill check.
     const uint32_t* lut2 = reinterpret_cast<const uint32_t*>(L.lut);
     const int psh = 32 - pair_bits, r2 = kDecPairBitsMax - pair_bits;
+    const char* lut2b = reinterpret_cast<const char*>(lut2 + rep2);
     uint32_t bad2 = 0;
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
@@ -1539,10 +1541,10 @@ __device__ __forceinline__ uint32_t decode_segment(const LT& L, const DecIn<STAG
 #endif
         GHF_REFILL();
         const uint32_t va = (uint32_t)((W << o) >> 32);
-        const uint32_t ea = lut2[((va >> psh) << r2) | rep2];
+        const uint32_t ea = *reinterpret_cast<const uint32_t*>(lut2b + ((va >> psh) << (r2 + 2)));
         o += (ea >> 16) & 31u;
         const uint32_t vb = (uint32_t)((W << o) >> 32);
-        const uint32_t eb = lut2[((vb >> psh) << r2) | rep2];
+        const uint32_t eb = *reinterpret_cast<const uint32_t*>(lut2b + ((vb >> psh) << (r2 + 2)));
         o += (eb >> 16) & 31u;
         bad2 |= ea | eb;
         wq[k] = __builtin_amdgcn_perm(eb, ea, 0x05040100u);  // {ea.sym0, ea.sym1, eb.sym0, eb.sym1}
