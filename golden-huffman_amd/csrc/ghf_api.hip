@@ -282,14 +282,16 @@ int ghf_histogram(ghf_ctx* c, const uint8_t* d_in, size_t n, uint64_t* d_hist) {
   return GHF_OK;
 }
 
-int ghf_build_code(ghf_ctx* c, const uint64_t* d_hist, ghf_code* d_code) {
-  if (!c || !d_hist || !d_code) return GHF_E_INVAL;
+int ghf_build_code_ex(ghf_ctx* c, const uint64_t* d_hist, ghf_code* d_code, unsigned flags) {
+  if (!c || !d_hist || !d_code || (flags & ~(unsigned)GHF_CODE_LIMIT)) return GHF_E_INVAL;
   GHF_HIP(c, hipSetDevice(c->device));
-  launch_build_code(d_hist, d_code, c->d_status, c->stream);
+  launch_build_code(d_hist, d_code, c->d_status, flags, c->stream);
   GHF_HIP(c, hipGetLastError());
   if (c->plan_code == d_code) c->plan_in = nullptr;  // tables changed: any cached plan is stale
   return GHF_OK;
 }
+
+int ghf_build_code(ghf_ctx* c, const uint64_t* d_hist, ghf_code* d_code) { return ghf_build_code_ex(c, d_hist, d_code, 0); }
 
 int ghf_write_header(ghf_ctx* c, const ghf_code* d_code, uint8_t* d_out, size_t cap) {
   if (!c || !d_code || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 3u)) return GHF_E_INVAL;
@@ -363,13 +365,18 @@ int ghf_shard_start_bit(ghf_ctx* c, const ghf_code* d_code, const uint64_t* d_to
 
 int ghf_compress(ghf_ctx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes,
                  ghf_code* d_code, const ghf_index* index) {
+  return ghf_compress_ex(c, d_in, n, d_out, cap, d_out_bytes, d_code, index, 0);
+}
+
+int ghf_compress_ex(ghf_ctx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes,
+                    ghf_code* d_code, const ghf_index* index, unsigned code_flags) {
   if (!c || !d_out || (n && !d_in)) return GHF_E_INVAL;
   if (n == 0) return fail(c, GHF_E_EMPTY, "empty input is undefined in the reference; refused");
   if (!aligned16(d_out)) return fail(c, GHF_E_INVAL, "d_out must be 16-byte aligned");
   ghf_code* code = d_code ? d_code : c->d_code;
   int rc;
   if ((rc = ghf_histogram(c, d_in, n, c->d_hist))) return rc;   // compressor.h:63
-  if ((rc = ghf_build_code(c, c->d_hist, code))) return rc;     // compressor.h:64
+  if ((rc = ghf_build_code_ex(c, c->d_hist, code, code_flags))) return rc;  // compressor.h:64
   if ((rc = ghf_encode_plan(c, d_in, n, code, c->d_u64))) return rc;
   // compressor.h:70 + :72 -- the header rides along with the emit launches
   if ((rc = ghf_encode_emit(c, d_in, n, code, nullptr, GHF_EMIT_LAST | GHF_EMIT_HEADER, d_out, cap, index, c->d_u64 + 1))) return rc;

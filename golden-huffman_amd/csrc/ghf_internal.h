@@ -122,7 +122,7 @@ void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_segs
 constexpr size_t kHistAccWords = 32 * 256 + 16 + 16 * 16;
 void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, uint32_t* d_chunk_hist,
                       uint64_t* d_hist, uint64_t* d_acc, hipStream_t s);
-void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, hipStream_t s);
+void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, uint32_t flags, hipStream_t s);
 void launch_write_header(const ghf_code* d_code, uint8_t* d_out, uint64_t cap, int* d_status, hipStream_t s);
 void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, const uint32_t* d_chunk_hist,
                  const ghf_code* d_code, uint64_t* d_chunk_off, uint64_t* d_total_bits, hipStream_t s);

@@ -377,9 +377,88 @@ struct CodeLds {
   uint32_t num[40];
 };
 
+// SURVEY 8(f) N4, opt-in (GHF_CODE_LIMIT): where the reference cannot go (a code longer than 32 bits,
+// include/canonical_huff_encoder.h:43-44) the lengths are replaced by the optimal 32-bit-limited ones
+// (package-merge; definition and tie rules: oracle/huff_oracle.c orc_limit_lengths).  Rare and small (<= 257 leaves,
+// 32 levels): ranking is done by all lanes, the merges by lane 0.
+struct LimitLds {
+  unsigned long long w[2][2 * GHF_NSYM];
+  uint8_t is_leaf[33][2 * GHF_NSYM];
+  uint16_t order[GHF_NSYM + 3];
+  uint16_t len_of[34], taken[34];
+  uint32_t newlen[GHF_NSYM + 3];
+  int n;
+};
+
+__device__ void limit_lengths_32(LimitLds& Q, const long long* freq, const uint32_t (&len)[5], int lane) {
+  constexpr int kLimit = 32;
+  // order: present symbols by (frequency ascending, index ascending)
+  if (lane == 0) Q.n = 0;
+  __syncthreads();
+#pragma unroll 1
+  for (int j = 0; j < 5; ++j) {
+    const int s = lane + 64 * j;
+    if (s >= GHF_NSYM || len[j] == 0) continue;
+    const long long f = freq[s];
+    int rank = 0;
+    for (int t = 0; t < GHF_NSYM; ++t) {
+      const long long g = freq[t];
+      rank += (g != 0) && (g < f || (g == f && t < s));
+    }
+    Q.order[rank] = (uint16_t)s;
+    atomicAdd(&Q.n, 1);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    const int n = Q.n;
+    int prev_n = 0, cur = 0;
+    for (int d = kLimit; d >= 1; --d) {
+      const unsigned long long* pw = Q.w[cur ^ 1];
+      unsigned long long* cw = Q.w[cur];
+      const int npk = prev_n / 2;
+      int li = 0, pi = 0, k = 0;
+      while (li < n || pi < npk) {
+        const unsigned long long lw = li < n ? (unsigned long long)freq[Q.order[li]] : ~0ull;
+        const unsigned long long pk = pi < npk ? pw[2 * pi] + pw[2 * pi + 1] : ~0ull;
+        if (li < n && (pi >= npk || lw <= pk)) {
+          cw[k] = lw;
+          Q.is_leaf[d][k] = 1;
+          ++li;
+        } else {
+          cw[k] = pk;
+          Q.is_leaf[d][k] = 0;
+          ++pi;
+        }
+        ++k;
+      }
+      Q.len_of[d] = (uint16_t)k;
+      prev_n = k;
+      cur ^= 1;
+    }
+    int need = 2 * n - 2;
+    for (int d = 1; d <= kLimit; ++d) {
+      if (need > (int)Q.len_of[d]) need = Q.len_of[d];
+      int leaves = 0;
+      for (int k = 0; k < need; ++k) leaves += Q.is_leaf[d][k];
+      Q.taken[d] = (uint16_t)leaves;
+      need = 2 * (need - leaves);
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < GHF_NSYM; i += 64) Q.newlen[i] = 0;
+  __syncthreads();
+  for (int i = lane; i < Q.n; i += 64) {
+    uint32_t l = 0;
+    for (int d = 1; d <= kLimit; ++d) l += i < (int)Q.taken[d];
+    Q.newlen[Q.order[i]] = l;
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __restrict__ hist, ghf_code* __restrict__ out,
-                                                   int* __restrict__ status) {
+                                                   int* __restrict__ status, uint32_t flags) {
   __shared__ HeapLds heap;
+  __shared__ LimitLds Q;
   __shared__ long long freq[GHF_NSYM + 3];
   __shared__ CodeLds cl;
   __shared__ int s_ndata;
@@ -460,10 +539,26 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
     const uint32_t o = __shfl_xor(mx, d, 64);
     mx = o > mx ? o : mx;
   }
-  const int max_len = (int)mx;  // .cc:343
-  if (max_len > 32) {           // include/canonical_huff_encoder.h:43-44: the reference cannot write such codes
-    if (lane == 0) latch_status(status, GHF_E_CODELEN);
-    return;
+  int max_len = (int)mx;  // .cc:343
+  if (max_len > 32) {     // include/canonical_huff_encoder.h:43-44: the reference cannot write such codes
+    if (!(flags & GHF_CODE_LIMIT)) {
+      if (lane == 0) latch_status(status, GHF_E_CODELEN);
+      return;
+    }
+    limit_lengths_32(Q, freq, len, lane);
+    mx = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int s = lane + 64 * j;
+      len[j] = s < GHF_NSYM ? Q.newlen[s] : 0u;
+      mx = len[j] > mx ? len[j] : mx;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t o = __shfl_xor(mx, d, 64);
+      mx = o > mx ? o : mx;
+    }
+    max_len = (int)mx;
   }
 
   // ---- K3: do_gen_encode, canonical_huff_encoder.cc:69-141 ----
@@ -517,9 +612,9 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
     reinterpret_cast<uint32_t*>(out)[i] = reinterpret_cast<const uint32_t*>(&cl.code)[i];
 }
 
-void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, hipStream_t s) {
+void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, uint32_t flags, hipStream_t s) {
   hipLaunchKernelGGL(k_build_code, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(d_hist), d_code,
-                     d_status);
+                     d_status, flags);
 }
 
 // ------------------------------------------------------------------------------------------------

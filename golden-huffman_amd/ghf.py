@@ -9,6 +9,7 @@ EMIT_LAST = 1
 EMIT_REBASE = 2
 EMIT_HEADER = 4
 INDEX_NO_END_MARK = 1
+CODE_LIMIT = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GHF_LIB") or os.path.join(_HERE, "lib", "libghf.so")  # GHF_LIB: experiment builds only
@@ -99,7 +100,7 @@ EXPORTS = [
     "ghf_write_header", "ghf_header_bytes", "ghf_encode_plan", "ghf_encode_emit", "ghf_compress", "ghf_compress_bound",
     "ghf_chunk_symbols", "ghf_index_alloc", "ghf_index_free", "ghf_parse_header", "ghf_decode", "ghf_decoded_size",
     "ghf_shard_start_bit", "ghf_crs_build_code", "ghf_crs_compress", "ghf_crs_compress_bound", "ghf_crs_parse_header",
-    "ghf_crs_decode", "ghf_crs_decoded_size",
+    "ghf_crs_decode", "ghf_crs_decoded_size", "ghf_build_code_ex", "ghf_compress_ex",
 ]
 
 _lib = None
@@ -156,6 +157,8 @@ def lib():
     L.ghf_decode.argtypes = [vp, vp, sz, vp, C.POINTER(Index), vp, sz, vp]
     L.ghf_decoded_size.argtypes = [vp, vp, sz, vp, C.POINTER(u64)]
     L.ghf_shard_start_bit.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.ghf_build_code_ex.argtypes = [vp, vp, vp, C.c_uint]
+    L.ghf_compress_ex.argtypes = [vp, vp, sz, vp, sz, vp, vp, C.POINTER(Index), C.c_uint]
     L.ghf_crs_build_code.argtypes = [vp, vp, vp, vp]
     L.ghf_crs_compress.argtypes = [vp, vp, sz, vp, sz, vp, vp, C.POINTER(Index)]
     L.ghf_crs_compress_bound.argtypes = [sz]
@@ -272,9 +275,12 @@ class Context:
         self._chk(self.L.ghf_histogram(self.h, d_in.data_ptr(), n, hist.data_ptr()), "ghf_histogram")
         return hist
 
-    def build_code(self, d_hist, d_code=None):
+    def build_code(self, d_hist, d_code=None, flags=0):
         d_code = self.new_code() if d_code is None else d_code
-        self._chk(self.L.ghf_build_code(self.h, d_hist.data_ptr(), d_code.data_ptr()), "ghf_build_code")
+        if flags:
+            self._chk(self.L.ghf_build_code_ex(self.h, d_hist.data_ptr(), d_code.data_ptr(), flags), "ghf_build_code_ex")
+        else:
+            self._chk(self.L.ghf_build_code(self.h, d_hist.data_ptr(), d_code.data_ptr()), "ghf_build_code")
         return d_code
 
     def write_header(self, d_code, d_out):
@@ -312,7 +318,7 @@ class Context:
     def index_free(self, idx):
         self.L.ghf_index_free(self.h, C.byref(idx))
 
-    def compress(self, d_in, d_out=None, d_code=None, index=None, n=None):
+    def compress(self, d_in, d_out=None, d_code=None, index=None, n=None, code_flags=0):
         """whole single-GPU pipeline, no host sync. -> (d_out, d_out_bytes[1] int64 device, d_code)"""
         n = d_in.numel() if n is None else n
         if d_out is None:
@@ -320,6 +326,12 @@ class Context:
         if d_code is None:
             d_code = self.new_code()
         nbytes = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
+        if code_flags:
+            self._chk(
+                self.L.ghf_compress_ex(self.h, d_in.data_ptr(), n, d_out.data_ptr(), d_out.numel(), nbytes.data_ptr(),
+                                       d_code.data_ptr(), None if index is None else C.byref(index), code_flags),
+                "ghf_compress_ex")
+            return d_out, nbytes, d_code
         self._chk(
             self.L.ghf_compress(self.h, d_in.data_ptr(), n, d_out.data_ptr(), d_out.numel(), nbytes.data_ptr(),
                                 d_code.data_ptr(), None if index is None else C.byref(index)),

@@ -172,6 +172,20 @@ int ghf_decode(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, const
 int ghf_decoded_size(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code, uint64_t* n_out);
 
 /* ------------------------------------------------------------------------------------------------
+ * inputs on which the reference is undefined because a code would be longer than 32 bits
+ * (include/canonical_huff_encoder.h:43-44; needs > 14.9 M bytes with Fibonacci-like counts).  With GHF_CODE_LIMIT
+ * the code lengths are then replaced by the OPTIMAL lengths under a 32-bit limit (package-merge; leaves ordered by
+ * (count ascending, byte value ascending), a leaf before a package of equal weight), and the usual canonical
+ * assignment (include/canonical_huff_encoder.cc:69-141) follows: the result is an ordinary .crs2 that the
+ * reference's decoders read.  Whenever the reference-exact code fits 32 bits the flag changes nothing, so the
+ * default output stays bit-exact.
+ * ------------------------------------------------------------------------------------------------ */
+#define GHF_CODE_LIMIT 1u
+int ghf_build_code_ex(ghf_ctx* ctx, const uint64_t* d_hist, ghf_code* d_code, unsigned flags);
+int ghf_compress_ex(ghf_ctx* ctx, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes,
+                    ghf_code* d_code, const ghf_index* index, unsigned code_flags);
+
+/* ------------------------------------------------------------------------------------------------
  * the `.crs` format -- Compressor<NormalHuffEncoder<>> / Decompressor<NormalHuffDecoder<>>
  * (include/normal_huff_encoder.h, include/huff_tree.h, include/huff_tree.cc).  Same histogram (256 byte values,
  * no end mark), the Huffman TREE itself defines the codes ('0' = left = first popped, '1' = right), the file is

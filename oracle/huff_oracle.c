@@ -519,3 +519,104 @@ int orc_crs_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, si
   *out_n = no;
   return 0;
 }
+
+/* ================================================================== SURVEY 8(f) N4: length-limited codes (opt-in)
+ * NOT a restatement of the reference: include/canonical_huff_encoder.h:43-44 simply cannot represent a code longer
+ * than 32 bits, so on such inputs the reference is undefined.  This is the definition libghf.so's opt-in
+ * GHF_CODE_LIMIT follows, restated independently so that the GPU result can be checked; what pins it to the
+ * reference is (a) inputs whose codes fit are untouched (bit-exact as before) and (b) the reference's own DECODER
+ * reads the limited streams back (tests/test_gpu_limit.py, compiled reference).
+ *
+ * Method: package-merge (Larmore & Hirschberg 1990), the optimal length-limited prefix code.  Leaves sorted by
+ * (frequency ascending, index ascending); for each level d = limit .. 1 the list of level d is the merge, by
+ * weight, of the leaves with the "packages" (sums of consecutive pairs) of level d + 1, a leaf going first on a
+ * tie; the first 2n - 2 items of level 1 are taken, every package among the taken items of a level stands for two
+ * items of the next one, and a leaf's code length is the number of levels in which it was taken. */
+int orc_limit_lengths(const int64_t hist[ORC_NSYM], uint32_t length[ORC_NSYM], int limit) {
+  int order[ORC_NSYM], n = 0, mx = 0;
+  for (int i = 0; i < ORC_NSYM; i++)
+    if (length[i]) {
+      order[n++] = i;
+      if ((int)length[i] > mx) mx = (int)length[i];
+    }
+  if (mx <= limit || n < 2) return mx;
+  for (int a = 1; a < n; a++) { /* insertion sort: n <= 257 */
+    int v = order[a], b = a - 1;
+    while (b >= 0 && (hist[order[b]] > hist[v] || (hist[order[b]] == hist[v] && order[b] > v))) {
+      order[b + 1] = order[b];
+      b--;
+    }
+    order[b + 1] = v;
+  }
+  static uint64_t w[2][2 * ORC_NSYM];      /* weights of the current / previous level's list */
+  static uint8_t is_leaf[66][2 * ORC_NSYM]; /* per level: item k is a leaf */
+  static int len_of[66];
+  int prev_n = 0, cur = 0;
+  for (int d = limit; d >= 1; d--) {
+    const uint64_t* pw = w[cur ^ 1];
+    uint64_t* cw = w[cur];
+    int npk = prev_n / 2, li = 0, pi = 0, k = 0;
+    while (li < n || pi < npk) {
+      uint64_t lw = li < n ? (uint64_t)hist[order[li]] : ~0ull;
+      uint64_t pk = pi < npk ? pw[2 * pi] + pw[2 * pi + 1] : ~0ull;
+      if (li < n && (pi >= npk || lw <= pk)) {
+        cw[k] = lw;
+        is_leaf[d][k] = 1;
+        li++;
+      } else {
+        cw[k] = pk;
+        is_leaf[d][k] = 0;
+        pi++;
+      }
+      k++;
+    }
+    len_of[d] = k;
+    prev_n = k;
+    cur ^= 1;
+  }
+  int need = 2 * n - 2, taken[66];
+  for (int d = 1; d <= limit; d++) {
+    if (need > len_of[d]) need = len_of[d];
+    int leaves = 0;
+    for (int k = 0; k < need; k++) leaves += is_leaf[d][k];
+    taken[d] = leaves;
+    need = 2 * (need - leaves);
+  }
+  int newmax = 0;
+  for (int i = 0; i < n; i++) {
+    uint32_t l = 0;
+    for (int d = 1; d <= limit; d++) l += i < taken[d];
+    length[order[i]] = l;
+    if ((int)l > newmax) newmax = (int)l;
+  }
+  return newmax;
+}
+
+/* orc_build_code with the opt-in limit: identical to orc_build_code whenever that one succeeds */
+int orc_build_code_limited(const int64_t hist_in[ORC_NSYM], orc_code* c, int limit) {
+  int64_t hist[ORC_NSYM];
+  int nz = 0;
+  memcpy(hist, hist_in, sizeof hist);
+  for (int i = 0; i < 256; i++) nz += hist[i] != 0;
+  if (nz == 0) return -1;
+  memset(c, 0, sizeof *c);
+  c->max_len = orc_code_lengths(hist, c->length); /* mutates hist: use the caller's counts for the ordering */
+  if (c->max_len > limit) c->max_len = orc_limit_lengths(hist_in, c->length, limit);
+  orc_canonical(c);
+  return 0;
+}
+
+int orc_compress_limited(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_n, int limit) {
+  int64_t hist[ORC_NSYM];
+  orc_code c;
+  orc_histogram(in, n, hist);
+  int rc = orc_build_code_limited(hist, &c, limit);
+  if (rc) return rc;
+  size_t hs = orc_header_size(&c);
+  if (cap < hs) return -3;
+  orc_write_header(&c, out);
+  size_t bs = orc_encode_body(in, n, &c, out + hs, cap - hs);
+  if (bs == (size_t)-1) return -3;
+  *out_n = hs + bs;
+  return 0;
+}

@@ -91,6 +91,11 @@ size_t orc_crs_bound(size_t n);
 int orc_crs_compress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_n);
 int orc_crs_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_n);
 
+/* ---------------------------------------------------------------- opt-in length limit (not reference behaviour) */
+int orc_limit_lengths(const int64_t hist[ORC_NSYM], uint32_t length[ORC_NSYM], int limit);
+int orc_build_code_limited(const int64_t hist_in[ORC_NSYM], orc_code* c, int limit);
+int orc_compress_limited(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_n, int limit);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,10 @@ def lib():
         L.orc_pack_at.restype = C.c_uint64
         L.orc_body_bits.argtypes = [C.POINTER(C.c_int64), C.POINTER(OrcCode)]
         L.orc_body_bits.restype = C.c_uint64
+        L.orc_build_code_limited.argtypes = [C.POINTER(C.c_int64), C.POINTER(OrcCode), C.c_int]
+        L.orc_build_code_limited.restype = C.c_int
+        L.orc_compress_limited.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
+        L.orc_compress_limited.restype = C.c_int
         L.orc_crs_build_tree.argtypes = [C.POINTER(C.c_int64), C.POINTER(OrcTree)]
         L.orc_crs_build_tree.restype = C.c_int
         L.orc_crs_codes.argtypes = [C.POINTER(OrcTree), C.POINTER(OrcCrsCode)]
@@ -178,6 +182,27 @@ def parse_header(crs2):
     if not hs:
         raise ValueError("bad .crs2 header")
     return c, hs
+
+
+# ------------------------------------------------------------------ opt-in length limit
+def build_code_limited(hist, limit=32):
+    h = np.ascontiguousarray(hist, dtype=np.int64)
+    c = OrcCode()
+    rc = lib().orc_build_code_limited(h.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(c), limit)
+    if rc:
+        raise ValueError("orc_build_code_limited rc=%d" % rc)
+    return c
+
+
+def compress_limited(data, limit=32):
+    a, p = _u8(data)
+    cap = lib().orc_compress_bound(a.size) + a.size * 3  # limited codes may be longer than 9 bits on average
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().orc_compress_limited(p, a.size, out.ctypes.data, cap, C.byref(n), limit)
+    if rc:
+        raise ValueError("orc_compress_limited rc=%d" % rc)
+    return out[: n.value].copy()
 
 
 # ------------------------------------------------------------------ .crs (NormalHuffEncoder)

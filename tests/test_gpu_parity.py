@@ -401,3 +401,22 @@ def test_nonstationary_stream_takes_the_unstaged_path(env):
     ctx.sync()
     assert int(n2.item()) == data.size and np.array_equal(out2[: data.size].cpu().numpy(), data)
     ctx.index_free(idx)
+
+
+def test_decode_into_an_unaligned_output_pointer(env):
+    """K7's fast path stores 16 bytes at a time; an output pointer that is not 16-byte aligned takes the byte-store
+    path instead (same for K6 + K7 without the side-car)."""
+    ghf, ctx, torch = env
+    data = dg.zipf_bytes(300001, seed=21)
+    _, d_out, nb, d_code, idx = run_compress(ghf, ctx, torch, data)
+    big = torch.zeros(data.size + 64, dtype=torch.uint8, device="cuda")
+    for off in (1, 7, 8):
+        dst = big[off : off + data.size + 16]
+        assert dst.data_ptr() % 16 == off
+        back, nout = ctx.decode(d_out, nb, d_code, idx, d_out=dst)
+        ctx.sync()
+        assert int(nout.item()) == data.size and np.array_equal(back[: data.size].cpu().numpy(), data), off
+    back, nout = ctx.decode(d_out, nb, d_code, None, d_out=big[3 : 3 + data.size + 16])
+    ctx.sync()
+    assert int(nout.item()) == data.size and np.array_equal(back[: data.size].cpu().numpy(), data)
+    ctx.index_free(idx)
