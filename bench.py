@@ -138,8 +138,9 @@ def main():
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         ctx_side = ghf.Context(local_rank)  # same device, queues on the side stream
-    hists = [torch.empty(ghf.NSYM, dtype=torch.int64, device="cuda") for _ in range(2)]
-    codes = [ctx.new_code(), ctx.new_code()]
+    DEPTH = 3  # steps in flight: emit+decode of step i, code build of steps i+1 and i+2
+    hists = [torch.empty(ghf.NSYM, dtype=torch.int64, device="cuda") for _ in range(DEPTH)]
+    codes = [ctx.new_code() for _ in range(DEPTH)]
     last_rank = rank == world - 1
     emit_flags = (ghf.EMIT_LAST if last_rank else 0) | (ghf.EMIT_REBASE if rank > 0 else ghf.EMIT_HEADER)  # rank 0 writes the header
 
@@ -177,14 +178,14 @@ def main():
 
     def front(i, record):
         """histogram (+ all-reduce) of step i on the main stream, code build on the side stream"""
-        h, c = hists[i & 1], codes[i & 1]
+        h, c = hists[i % DEPTH], codes[i % DEPTH]
         timed("histogram", record, lambda: ctx.histogram(d_in, out=h))
-        if world > 1:
-            timed("allreduce", record, lambda: all_reduce_sum(h[:256]))
         hdone = torch.cuda.Event()
         hdone.record(main)
         with torch.cuda.stream(side):
             side.wait_event(hdone)
+            if world > 1:  # the 2 KiB all-reduce rides on the side stream too: the main stream never waits for it
+                timed("allreduce", record, lambda: all_reduce_sum(h[:256]))
             timed("build_code", record, lambda: ctx_side.build_code(h, c))
             kdone = torch.cuda.Event()
             kdone.record(side)
@@ -192,11 +193,12 @@ def main():
 
     def run(K, record):
         end = None
-        kdone = front(0, record)
+        ahead = DEPTH - 1  # the one-wave code build takes about as long as a whole step's streaming kernels: start it two steps early
+        pending = {j: front(j, record and (j % 4 == 1 or K <= 4)) for j in range(min(ahead, K))}
         for i in range(K):
-            c = codes[i & 1]
+            c = codes[i % DEPTH]
             rec = record and (i % 4 == 1 or K <= 4)  # events on every 4th step: keeps the host ahead of the GPU
-            main.wait_event(kdone)
+            main.wait_event(pending.pop(i))
             total = timed("plan", rec, lambda: ctx.encode_plan(d_in, c, total=t_total))
             if world > 1:
                 def gather():
@@ -205,8 +207,8 @@ def main():
                 start_bit = timed("allgather", rec, gather)
             else:
                 start_bit = None
-            if i + 1 < K:
-                kdone = front(i + 1, record and ((i + 1) % 4 == 1 or K <= 4))  # its K2 overlaps the emit + decode below
+            if i + ahead < K:  # histogram of step i+2 now; its all-reduce and code build overlap the next two steps' streaming kernels
+                pending[i + ahead] = front(i + ahead, record and ((i + ahead) % 4 == 1 or K <= 4))
             end = timed("emit", rec, lambda: ctx.encode_emit(d_in, c, out, start_bit=start_bit, flags=emit_flags, index=index, end=t_end))
             timed("decode", rec, lambda: ctx.decode(out, bound, c, index, d_out=dec, nbytes=t_nbytes))
         return end
@@ -278,7 +280,7 @@ def main():
                        "baseline_config": "configs[1]" if (world == 1 and args.kind == "uniform" and args.mib == 256) else "configs[3]-style shard",
                        "bytes_per_gpu": n, "compressed_bytes_per_gpu": comp_bytes, "parallelism": "shard%d" % world,
                        "collectives": "none" if world == 1 else "all_reduce(256 x i64) + all_gather(1 x i64) per step",
-                       "pipeline": "steps software-pipelined: the one-wave code build of step i+1 runs on a side stream under the emit+decode of step i"},
+                       "pipeline": "steps software-pipelined, 3 in flight: the histogram all-reduce and the one-wave code build of steps i+1 and i+2 run on a side stream under the emit+decode of step i"},
             "encode_GBps": round(n * world / (enc_ms * 1e-3) / 1e9, 3), "decode_GBps": round(n * world / (stage_ms["decode"] * 1e-3) / 1e9, 3),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

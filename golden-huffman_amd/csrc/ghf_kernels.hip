@@ -372,9 +372,11 @@ __device__ __forceinline__ void wave_heap_push(HeapLds& h, int n, u64t e, int la
   if (lane <= t) h.slot[aj + 1] = (lane < t) ? up : e;
 }
 
-struct CodeLds {
-  ghf_code code;
+struct CodeLds {  // the small per-length tables of K3; the per-symbol arrays go straight to global memory
   uint32_t num[40];
+  uint32_t first_code[64];
+  uint32_t start_pos[64];
+  int32_t min_len, max_len;
 };
 
 // SURVEY 8(f) N4, opt-in (GHF_CODE_LIMIT): where the reference cannot go (a code longer than 32 bits,
@@ -387,11 +389,13 @@ struct LimitLds {
   uint16_t order[GHF_NSYM + 3];
   uint16_t len_of[34], taken[34];
   uint32_t newlen[GHF_NSYM + 3];
+  long long freq[GHF_NSYM + 3];
   int n;
 };
 
-__device__ void limit_lengths_32(LimitLds& Q, const long long* freq, const uint32_t (&len)[5], int lane) {
+__device__ void limit_lengths_32(LimitLds& Q, const uint32_t (&len)[5], int lane) {
   constexpr int kLimit = 32;
+  const long long* freq = Q.freq;
   // order: present symbols by (frequency ascending, index ascending)
   if (lane == 0) Q.n = 0;
   __syncthreads();
@@ -455,21 +459,36 @@ __device__ void limit_lengths_32(LimitLds& Q, const long long* freq, const uint3
   __syncthreads();
 }
 
+// LIMIT = the GHF_CODE_LIMIT instantiation: it alone carries LimitLds (26 KiB).  The default one stays small enough
+// in LDS to be scheduled next to the streaming kernels of a pipelined caller instead of waiting for a CU to drain.
+struct NoLimitLds {};
+template <bool LIMIT>
 __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __restrict__ hist, ghf_code* __restrict__ out,
-                                                   int* __restrict__ status, uint32_t flags) {
+                                                   int* __restrict__ status) {
   __shared__ HeapLds heap;
-  __shared__ LimitLds Q;
-  __shared__ long long freq[GHF_NSYM + 3];
+  __shared__ typename std::conditional<LIMIT, LimitLds, NoLimitLds>::type Q;
+  // one latency-bound wave among thousands of streaming ones (the other kernels of a pipelined caller share its CU):
+  // let the instruction arbiter of its SIMD prefer it
+  __builtin_amdgcn_s_setprio(3);
   __shared__ CodeLds cl;
   __shared__ int s_ndata;
   const int lane = threadIdx.x;
-  for (int s = lane; s < GHF_NSYM; s += 64) {
-    freq[s] = (long long)hist[s];
-    heap.cur[s] = (uint16_t)s;
+  // the 257 counts live in registers (lane l holds symbols l, l + 64, ..): LDS is kept under 7 KiB so that this wave
+  // fits on a CU next to K7's 153 KiB (or K5's, or K1's) instead of waiting for one of their workgroups to retire
+  long long fr[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int s = lane + 64 * j;
+    fr[j] = s < GHF_NSYM ? (long long)hist[s] : 0ll;
+    if constexpr (LIMIT) {
+      if (s < GHF_NSYM) Q.freq[s] = fr[j];
+    }
   }
+  for (int s = lane; s < GHF_NSYM; s += 64) heap.cur[s] = (uint16_t)s;
   for (int i = lane; i < GHF_NSYM + 256 + 7; i += 64) heap.parent[i] = 0;
-  for (int i = lane; i < (int)(sizeof(ghf_code) / 4); i += 64) reinterpret_cast<uint32_t*>(&cl.code)[i] = 0;
   if (lane < 40) cl.num[lane] = 0;
+  cl.first_code[lane] = 0;
+  cl.start_pos[lane] = 0;
   __syncthreads();
 
   // ---- K2: get_encoding_length, canonical_huff_encoder.cc:289-345.  The ORDER of heap operations is strictly
@@ -478,7 +497,7 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
   {
     int n = 0, ndata = 0;
     for (int s = 0; s < GHF_NSYM; ++s) {  // .cc:301-306: ascending index, zero counts skipped
-      const u64t f = wave_uniform((u64t)freq[s]);
+      const u64t f = (u64t)__shfl(fr[s >> 6], s & 63, 64);  // wave-uniform: readlane
       if (f) {
         wave_heap_push(heap, n, (f << 9) | (u64t)s, lane);  // priority_queue::push
         ++n;
@@ -541,24 +560,25 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
   }
   int max_len = (int)mx;  // .cc:343
   if (max_len > 32) {     // include/canonical_huff_encoder.h:43-44: the reference cannot write such codes
-    if (!(flags & GHF_CODE_LIMIT)) {
+    if constexpr (!LIMIT) {
       if (lane == 0) latch_status(status, GHF_E_CODELEN);
       return;
-    }
-    limit_lengths_32(Q, freq, len, lane);
-    mx = 0;
+    } else {
+      limit_lengths_32(Q, len, lane);
+      mx = 0;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int s = lane + 64 * j;
-      len[j] = s < GHF_NSYM ? Q.newlen[s] : 0u;
-      mx = len[j] > mx ? len[j] : mx;
-    }
+      for (int j = 0; j < 5; ++j) {
+        const int s = lane + 64 * j;
+        len[j] = s < GHF_NSYM ? Q.newlen[s] : 0u;
+        mx = len[j] > mx ? len[j] : mx;
+      }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const uint32_t o = __shfl_xor(mx, d, 64);
-      mx = o > mx ? o : mx;
+      for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(mx, d, 64);
+        mx = o > mx ? o : mx;
+      }
+      max_len = (int)mx;
     }
-    max_len = (int)mx;
   }
 
   // ---- K3: do_gen_encode, canonical_huff_encoder.cc:69-141 ----
@@ -566,29 +586,32 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
   for (int j = 0; j < 5; ++j) {
     const int s = lane + 64 * j;
     if (s < GHF_NSYM) {
-      cl.code.length[s] = len[j];
-      cl.code.symbol[s] = 0xFFFFFFFFu;  // .cc:88
+      out->length[s] = len[j];
+      out->codeword[s] = 0;
+      out->symbol[s] = 0xFFFFFFFFu;  // .cc:88
       if (len[j]) atomicAdd(&cl.num[len[j]], 1u);  // .cc:85-87
     }
   }
-  __syncthreads();
+  __syncthreads();  // (also orders the symbol[] defaults above before the slots written below)
   const uint32_t num = (lane >= 1 && lane <= max_len) ? cl.num[lane] : 0u;
   const unsigned long long nzmask = __ballot(num != 0);
   const int min_len = __ffsll((long long)nzmask) - 1;                 // .cc:93-98
   const uint32_t spos = wave_incl_scan_u32(num, lane) - num;          // .cc:104-105 start_pos[i] = sum num[1..i-1]
-  if (lane >= 1 && lane <= max_len) cl.code.start_pos[lane] = spos;
+  if (lane >= 1 && lane <= max_len) cl.start_pos[lane] = spos;
   if (lane == 0) {                                                     // .cc:109-121
     uint32_t fc = 0;
-    cl.code.first_code[max_len] = 0;
+    cl.first_code[max_len] = 0;
     for (int i = max_len - 1; i >= 1; --i) {
       fc = (fc + cl.num[i + 1]) >> 1;
-      cl.code.first_code[i] = fc;
+      cl.first_code[i] = fc;
     }
-    for (int i = 1; i < min_len; ++i) cl.code.first_code[i] = 1024;
-    cl.code.min_len = min_len;
-    cl.code.max_len = max_len;
+    for (int i = 1; i < min_len; ++i) cl.first_code[i] = 1024;
+    out->min_len = min_len;
+    out->max_len = max_len;
   }
   __syncthreads();
+  out->first_code[lane] = cl.first_code[lane];  // 64 entries each, zero beyond max_len
+  out->start_pos[lane] = cl.start_pos[lane];
   // .cc:127-133: within a length, codes and symbol_[] slots go to symbols in ascending index order.
   // rank = (#same-length symbols in earlier 64-symbol rows) + (#same-length lanes below me in my row)
   uint32_t seen = 0;  // lane L holds how many symbols of length L were ranked so far
@@ -601,20 +624,19 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
       if (m) {
         const uint32_t r = before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         const int s = lane + 64 * j;
-        cl.code.codeword[s] = cl.code.first_code[L] + r;
-        cl.code.symbol[cl.code.start_pos[L] + r] = (uint32_t)s;
+        out->codeword[s] = cl.first_code[L] + r;
+        out->symbol[cl.start_pos[L] + r] = (uint32_t)s;
       }
       if (lane == L) seen += (uint32_t)__popcll(mask);
     }
   }
-  __syncthreads();
-  for (int i = lane; i < (int)(sizeof(ghf_code) / 4); i += 64)
-    reinterpret_cast<uint32_t*>(out)[i] = reinterpret_cast<const uint32_t*>(&cl.code)[i];
 }
 
 void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, uint32_t flags, hipStream_t s) {
-  hipLaunchKernelGGL(k_build_code, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(d_hist), d_code,
-                     d_status, flags);
+  if (flags & GHF_CODE_LIMIT)
+    hipLaunchKernelGGL(k_build_code<true>, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(d_hist), d_code, d_status);
+  else
+    hipLaunchKernelGGL(k_build_code<false>, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(d_hist), d_code, d_status);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -638,6 +660,7 @@ __global__ __launch_bounds__(64) void k_crs_build_code(const unsigned long long*
   __shared__ HeapLds heap;
   __shared__ TreeLds T;
   __shared__ ghf_tree tree;
+  __builtin_amdgcn_s_setprio(3);  // see k_build_code
   const int lane = threadIdx.x;
   for (int s = lane; s < GHF_NSYM; s += 64) heap.cur[s] = (uint16_t)s;
   for (int i = lane; i < GHF_NSYM + 256 + 7; i += 64) {
