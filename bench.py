@@ -121,7 +121,6 @@ def main():
     bound = ghf.compress_bound(n)
     out = ctx.empty_u8(bound)
     dec = ctx.empty_u8(n)
-    d_code = ctx.new_code()
     index = ctx.index_alloc(n)
     index.flags = 0 if rank == world - 1 else ghf.INDEX_NO_END_MARK  # only the last shard ends with the end mark
     torch.cuda.synchronize()
@@ -130,25 +129,28 @@ def main():
     acc_ms = {k: 0.0 for k in names}
     ev_log = []  # (name, start_event, end_event)
 
-    # The one-wavefront code build (K2) is latency-bound (a strictly sequential heap on 1 of 256 CUs); every other
-    # kernel streams through HBM on the whole chip.  So consecutive steps are software-pipelined: while step i is
-    # bit-packed and decoded on the main stream, the histogram of step i+1 has already run and its code is being
-    # built on a side stream.  Every step still does all of its work; only the first K2 of a run is exposed.
+    # The one-wavefront code build (K2) is latency-bound (a strictly sequential heap on 1 of 256 CUs) and takes about
+    # as long as all streaming kernels of a step together; the two collectives are latency-bound too.  So the steps
+    # are software-pipelined, three in flight: the main stream runs only the kernels that stream through HBM --
+    # histogram of step i+2, emit and decode of step i -- while a side stream runs, two steps ahead, the histogram
+    # all-reduce, the code build, the chunk pricing (K4) and the offset all-gather of step i+2.  Each step in flight
+    # has its own ghf context (= its own workspace: the per-chunk histogram K1 leaves for K4, the chunk offsets K4
+    # leaves for K5), which is also what pipelining over DIFFERENT input buffers needs.  Every step does all of its
+    # work inside the timed region.
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        ctx_side = ghf.Context(local_rank)  # same device, queues on the side stream
-    DEPTH = 3  # steps in flight: emit+decode of step i, code build of steps i+1 and i+2
+    DEPTH = 3
+    ahead = DEPTH - 1
+    ctxs = [ctx] + [ghf.Context(local_rank) for _ in range(DEPTH - 1)]
     hists = [torch.empty(ghf.NSYM, dtype=torch.int64, device="cuda") for _ in range(DEPTH)]
     codes = [ctx.new_code() for _ in range(DEPTH)]
-    last_rank = rank == world - 1
-    emit_flags = (ghf.EMIT_LAST if last_rank else 0) | (ghf.EMIT_REBASE if rank > 0 else ghf.EMIT_HEADER)  # rank 0 writes the header
-
-    t_total = torch.empty(1, dtype=torch.int64, device="cuda")
+    t_total = [torch.empty(1, dtype=torch.int64, device="cuda") for _ in range(DEPTH)]
+    t_totals = [torch.empty(max(world, 1), dtype=torch.int64, device="cuda") for _ in range(DEPTH)]
+    t_start = [torch.empty(1, dtype=torch.int64, device="cuda") for _ in range(DEPTH)]
     t_end = torch.empty(2, dtype=torch.int64, device="cuda")
     t_nbytes = torch.empty(1, dtype=torch.int64, device="cuda")
-    t_totals = torch.empty(max(world, 1), dtype=torch.int64, device="cuda")
-    t_start = torch.empty(1, dtype=torch.int64, device="cuda")
+    last_rank = rank == world - 1
+    emit_flags = (ghf.EMIT_LAST if last_rank else 0) | (ghf.EMIT_REBASE if rank > 0 else ghf.EMIT_HEADER)  # rank 0 writes the header
 
     def all_reduce_sum(t):
         if args.backend == "nccl":
@@ -177,46 +179,50 @@ def main():
         return r
 
     def front(i, record):
-        """histogram (+ all-reduce) of step i on the main stream, code build on the side stream"""
-        h, c = hists[i % DEPTH], codes[i % DEPTH]
-        timed("histogram", record, lambda: ctx.histogram(d_in, out=h))
+        """step i up to the point where its emit can start: K1 on the main stream; all-reduce, K2/K3, K4, all-gather
+        on the side stream.  Returns the event the main stream waits for before emit(i)."""
+        k = i % DEPTH
+        cx, h, c = ctxs[k], hists[k], codes[k]
+        cx.use_current_stream()  # main
+        timed("histogram", record, lambda: cx.histogram(d_in, out=h))
         hdone = torch.cuda.Event()
         hdone.record(main)
         with torch.cuda.stream(side):
             side.wait_event(hdone)
-            if world > 1:  # the 2 KiB all-reduce rides on the side stream too: the main stream never waits for it
+            cx.use_current_stream()  # side
+            if world > 1:
                 timed("allreduce", record, lambda: all_reduce_sum(h[:256]))
-            timed("build_code", record, lambda: ctx_side.build_code(h, c))
-            kdone = torch.cuda.Event()
-            kdone.record(side)
-        return kdone
+            timed("build_code", record, lambda: cx.build_code(h, c))
+            timed("plan", record, lambda: cx.encode_plan(d_in, c, total=t_total[k]))
+            if world > 1:
+                def gather():
+                    all_gather_1(t_totals[k], t_total[k])
+                    cx.shard_start_bit(c, t_totals[k], world, rank, out=t_start[k])
+                timed("allgather", record, gather)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        return ready
 
     def run(K, record):
         end = None
-        ahead = DEPTH - 1  # the one-wave code build takes about as long as a whole step's streaming kernels: start it two steps early
-        pending = {j: front(j, record and (j % 4 == 1 or K <= 4)) for j in range(min(ahead, K))}
+        rec_of = lambda j: record and (j % 4 == 1 or K <= 4)  # events on every 4th step: keeps the host ahead of the GPU
+        pending = {j: front(j, rec_of(j)) for j in range(min(ahead, K))}
         for i in range(K):
-            c = codes[i % DEPTH]
-            rec = record and (i % 4 == 1 or K <= 4)  # events on every 4th step: keeps the host ahead of the GPU
+            k = i % DEPTH
+            if i + ahead < K:
+                pending[i + ahead] = front(i + ahead, rec_of(i + ahead))
+            cx, c = ctxs[k], codes[k]
+            cx.use_current_stream()  # main
             main.wait_event(pending.pop(i))
-            total = timed("plan", rec, lambda: ctx.encode_plan(d_in, c, total=t_total))
-            if world > 1:
-                def gather():
-                    all_gather_1(t_totals, total)
-                    return ctx.shard_start_bit(c, t_totals, world, rank, out=t_start)
-                start_bit = timed("allgather", rec, gather)
-            else:
-                start_bit = None
-            if i + ahead < K:  # histogram of step i+2 now; its all-reduce and code build overlap the next two steps' streaming kernels
-                pending[i + ahead] = front(i + ahead, record and ((i + ahead) % 4 == 1 or K <= 4))
-            end = timed("emit", rec, lambda: ctx.encode_emit(d_in, c, out, start_bit=start_bit, flags=emit_flags, index=index, end=t_end))
-            timed("decode", rec, lambda: ctx.decode(out, bound, c, index, d_out=dec, nbytes=t_nbytes))
+            start_bit = t_start[k] if world > 1 else None
+            end = timed("emit", rec_of(i), lambda: cx.encode_emit(d_in, c, out, start_bit=start_bit, flags=emit_flags, index=index, end=t_end))
+            timed("decode", rec_of(i), lambda: cx.decode(out, bound, c, index, d_out=dec, nbytes=t_nbytes))
         return end
 
     end = run(max(args.warmup, 1), False)
     torch.cuda.synchronize()
-    ctx.sync()
-    ctx_side.sync()
+    for cx in ctxs:
+        cx.sync()
     if not args.no_verify:
         assert bool((dec[:n] == d_in).all().item()), "round trip mismatch"
     comp_bytes = int(end[1].item())
@@ -231,8 +237,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ctx.sync()  # raises if any stage latched an error
-    ctx_side.sync()
+    for cx in ctxs:
+        cx.sync()  # raises if any stage latched an error
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -280,7 +286,7 @@ def main():
                        "baseline_config": "configs[1]" if (world == 1 and args.kind == "uniform" and args.mib == 256) else "configs[3]-style shard",
                        "bytes_per_gpu": n, "compressed_bytes_per_gpu": comp_bytes, "parallelism": "shard%d" % world,
                        "collectives": "none" if world == 1 else "all_reduce(256 x i64) + all_gather(1 x i64) per step",
-                       "pipeline": "steps software-pipelined, 3 in flight: the histogram all-reduce and the one-wave code build of steps i+1 and i+2 run on a side stream under the emit+decode of step i"},
+                       "pipeline": "steps software-pipelined, 3 in flight (one ghf context each): main stream = histogram of step i+2, emit + decode of step i; side stream, two steps ahead = histogram all-reduce, one-wave code build, chunk pricing, offset all-gather"},
             "encode_GBps": round(n * world / (enc_ms * 1e-3) / 1e9, 3), "decode_GBps": round(n * world / (stage_ms["decode"] * 1e-3) / 1e9, 3),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -294,8 +300,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(d_in.cpu().numpy(), args.kind)
         print(json.dumps(res), flush=True)
     ctx.index_free(index)
-    ctx_side.close()
-    ctx.close()
+    for cx in reversed(ctxs):
+        cx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
