@@ -252,7 +252,12 @@ class HipCanonicalHuffEncoder<unsigned char> {
   // include/canonical_huff_encoder.cc:35-42
   void gen_encode() {
     d_code_.alloc(s_, sizeof(ghf_code));
-    s_.check(ghf_build_code(s_.ctx(), static_cast<const uint64_t*>(d_hist_.p), static_cast<ghf_code*>(d_code_.p)), "ghf_build_code");
+    // opt-in: set_code_limit(true) or GHF_CODE_LIMIT=1 in the environment replaces the reference's
+    // "undefined above 32 bits" by the optimal 32-bit-limited code; without it the behaviour is the reference's
+    const char* env = getenv("GHF_CODE_LIMIT");
+    const unsigned flags = (limit_ || (env && env[0] == '1')) ? GHF_CODE_LIMIT : 0u;
+    s_.check(ghf_build_code_ex(s_.ctx(), static_cast<const uint64_t*>(d_hist_.p), static_cast<ghf_code*>(d_code_.p), flags),
+             "ghf_build_code");
     s_.check(ghf_copy_d2h(s_.ctx(), &code_, d_code_.p, sizeof(ghf_code)), "ghf_copy_d2h");
     s_.sync("gen_encode");
   }
@@ -290,6 +295,7 @@ class HipCanonicalHuffEncoder<unsigned char> {
   }
 
   const ghf_code& code() const { return code_; }  // length_/codeword_/symbol_/... of the reference, for tests
+  void set_code_limit(bool on) { limit_ = on; }   // not in the reference: see gen_encode()
 
  private:
   HipCanonicalHuffEncoder(const HipCanonicalHuffEncoder&);
@@ -299,6 +305,7 @@ class HipCanonicalHuffEncoder<unsigned char> {
   FILE* outfile_;
   std::string infile_name_;
   size_t n_, cap_;
+  bool limit_ = false;
   detail::PinnedBuf h_out_;
   detail::DeviceBuf d_in_, d_hist_, d_code_, d_out_;
   detail::Stager stager_;

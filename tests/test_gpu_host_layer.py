@@ -133,3 +133,26 @@ def test_crs_errors_are_reported_not_undefined(tool, tmp_path):
     junk = tmp_path / "junk.crs"
     junk.write_bytes(b"\xff" * 4000)
     assert subprocess.run([tool, str(junk), "2"], capture_output=True, timeout=60).returncode == 1
+
+
+def test_code_limit_opt_in_through_the_host_layer(tool, tmp_path):
+    """a 14.9 MB file whose reference-exact code would need 33 bits.  Default: refused like the
+    reference's own limit (status 4); with GHF_CODE_LIMIT=1: an ordinary .crs2 that we, the oracle and -- where it
+    travelled along -- the compiled reference's decoder read back."""
+    import datagen as dg
+
+    data = dg.counts_to_bytes(dg.fib_counts(33), seed=5)
+    f = tmp_path / "fib33.bin"
+    data.tofile(f)
+    r = subprocess.run([tool, str(f), "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "error 4" in r.stderr
+    env = dict(os.environ, GHF_CODE_LIMIT="1")
+    assert subprocess.run([tool, str(f), "3"], env=env, timeout=120).returncode == 0
+    crs = np.fromfile(str(f) + ".crs2", dtype=np.uint8)
+    ref = orc.compress_limited(data, 32)
+    assert crs.size == ref.size and sha(crs) == sha(ref)
+    assert subprocess.run([tool, str(f) + ".crs2", "4"], timeout=120).returncode == 0
+    assert np.array_equal(np.fromfile(str(f) + ".crs2.de", dtype=np.uint8), data)
+    if orc.have_ref():
+        orc.ref_run(["d", str(f) + ".crs2", str(tmp_path / "ref.de")], timeout=300)
+        assert np.array_equal(np.fromfile(tmp_path / "ref.de", dtype=np.uint8), data)
