@@ -105,15 +105,11 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
     const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;
     const uint32_t cls = blockIdx.x % ncls;
     unsigned long long* tick = acc + 32 * 256 + 16 + cls * 16;
-    auto draw = [&]() -> uint32_t { return (uint32_t)atomicAdd(tick, 1ull) * ncls + cls; };  // thread 0 only
-    if (tid == 0) s_tick = draw();
-    __syncthreads();
-    uint32_t cur = s_tick;
-    __syncthreads();
-    if (tid == 0) s_tick = draw();
-    __syncthreads();
-    uint32_t nxt = s_tick;
-    __syncthreads();
+    // the first two chunks of a workgroup are fixed, so its first loads go out before any counter has answered;
+    // tickets number the chunks behind those 2 * gridDim.x
+    auto draw = [&]() -> uint32_t { return 2u * gridDim.x + (uint32_t)atomicAdd(tick, 1ull) * ncls + cls; };  // thread 0 only
+    uint32_t cur = blockIdx.x;
+    uint32_t nxt = blockIdx.x + gridDim.x;
     const uint32_t V = 1u << vlog;
     auto vptr = [&](uint32_t c, uint32_t j) -> const uint4* {
       if (c >= nfullchunks) c = nfullchunks - 1;  // past the end: redundant, harmless loads
@@ -1841,12 +1837,16 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
     if (lane == 0) t = atomicAdd(&P.dt->ticket[cls * 32], 1u);
     return t;
   };
+  // every wave's first three groups are fixed (no round trip to a counter before the first load can be issued: three
+  // dependent atomics on 16 counters cost the 4096 waves several microseconds of start-up); tickets number the rest
+  const uint64_t nwaves = (uint64_t)gridDim.x * kDec7Waves;
+  const uint64_t wid = (uint64_t)blockIdx.x * kDec7Waves + (uint64_t)wave;
   auto ticket_group = [&](unsigned int t) -> uint64_t {
-    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * ncls + cls;
+    return 3 * nwaves + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * ncls + cls;
   };
-  uint64_t group = ticket_group(ticket_issue());
+  uint64_t group = wid;
   if (group >= ngroups) return;
-  uint64_t g1 = ticket_group(ticket_issue()), g2 = ticket_group(ticket_issue());  // this wave's next two groups
+  uint64_t g1 = wid + nwaves, g2 = wid + 2 * nwaves;  // this wave's next two groups
   const uint64_t glast = ngroups - 1;
   auto clampg = [&](uint64_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
 
