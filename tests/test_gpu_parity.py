@@ -420,3 +420,21 @@ def test_decode_into_an_unaligned_output_pointer(env):
     ctx.sync()
     assert int(nout.item()) == data.size and np.array_equal(back[: data.size].cpu().numpy(), data)
     ctx.index_free(idx)
+
+
+@pytest.mark.parametrize("k,n", [(3, 300001), (7, 700001), (15, 1500001)])
+def test_foreign_stream_with_a_fixed_length_code(env, k, n):
+    """k equally frequent symbols + the end mark = 2^m leaves of equal depth: a code that never self-synchronises
+    (a decoder started off a boundary stays off it for ever).  K6 must still find every boundary -- the known start of
+    the body propagates -- and quickly."""
+    ghf, ctx, torch = env
+    rng = np.random.default_rng(k)
+    data = np.tile(np.arange(k, dtype=np.uint8), n // k + 1)[:n]
+    data[: n - n % k] = rng.permutation(data[: n - n % k])
+    ref = orc.compress(data)
+    code, hs = ghf.parse_header(ref)
+    assert code.min_len == code.max_len  # all 2^m leaves at depth m
+    d = to_dev(torch, np.concatenate([ref, np.zeros(32, np.uint8)]))
+    out, n2 = ctx.decode(d, ref.size, ctx.code_to_device(code), None, cap=n + 64)
+    ctx.sync()
+    assert int(n2.item()) == n and np.array_equal(out[:n].cpu().numpy(), data)
