@@ -488,8 +488,8 @@ int ghf_parse_header(const uint8_t* h, size_t n, ghf_code* code, size_t* header_
 
 // K6: rebuild the side-car of a stream that came without one (e.g. a .crs2 written by the reference).
 // Synchronises with the host a few times (convergence flag, symbol count); fills c->fidx.
-static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, size_t hdr, uint64_t end_bit, bool no_eof,
-                            size_t cap);
+static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, size_t hdr, uint64_t end_bit, int mode,
+                            size_t cap, uint32_t first_start = 0, uint64_t* landing = nullptr, int* has_end_mark = nullptr);
 
 static int rebuild_index(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code, size_t cap) {
   ghf_code* hc = new (std::nothrow) ghf_code;
@@ -502,19 +502,21 @@ static int rebuild_index(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
   if (max_len < 1 || max_len > 32) return fail(c, GHF_E_FORMAT, "bad max_len in tables");
   const size_t hdr = ghf_header_bytes(max_len);
   if (stream_bytes <= hdr) return fail(c, GHF_E_FORMAT, "stream shorter than its header");
-  return rebuild_index_at(c, d_stream, stream_bytes, hdr, (uint64_t)stream_bytes * 8, false, cap);
+  return rebuild_index_at(c, d_stream, stream_bytes, hdr, (uint64_t)stream_bytes * 8, 0, cap);
 }
 
 // K6 driver.  hdr = bytes in front of the first code; end_bit = one past the last bit that may belong to a code;
-// no_eof: the stream has no end mark and must end exactly at end_bit (.crs)
-static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, size_t hdr, uint64_t end_bit, bool no_eof,
-                            size_t cap) {
+// mode 0: .crs2 (ends with the end mark); 1: .crs (no end mark, must end exactly at end_bit); 2: a piece of a .crs2
+// whose first code boundary is assumed first_start bits behind hdr and whose last code may run past end_bit
+static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, size_t hdr, uint64_t end_bit, int mode,
+                            size_t cap, uint32_t first_start, uint64_t* landing, int* has_end_mark) {
+  const bool no_eof = mode == 1;
   SyncParams p;
   p.stream = d_stream;
   p.stream_bytes = stream_bytes;
   p.body_bit0 = (uint64_t)hdr * 8;
   p.end_bit = end_bit;
-  p.no_eof = no_eof ? 1u : 0u;
+  p.no_eof = (uint32_t)mode;
   p.dt = c->d_dt;
   p.nsub = (end_bit - p.body_bit0 + 511) / 512;
   const size_t ntiles = (p.nsub + 255) / 256;
@@ -543,6 +545,11 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
   p.changed = reinterpret_cast<uint32_t*>(c->d_u64 + 5);
   p.eof_sub = c->d_u64 + 4;
   GHF_HIP(c, hipMemsetAsync(p.start, 0, (p.nsub + 1) * 2, c->stream));
+  if (first_start) {
+    const uint16_t fs = (uint16_t)first_start;
+    GHF_HIP(c, hipMemcpyAsync(p.start, &fs, 2, hipMemcpyHostToDevice, c->stream));
+    GHF_HIP(c, hipStreamSynchronize(c->stream));  // fs lives on this stack frame
+  }
   GHF_HIP(c, hipMemsetAsync(p.used, 0xFF, p.nsub * 2, c->stream));
   GHF_HIP(c, hipMemsetAsync(p.eof, 0, p.nsub, c->stream));
   launch_store_u64(p.eof_sub, nullptr, p.nsub, c->stream);  // "none found"; k_sync_eof takes the minimum
@@ -563,6 +570,15 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
     // every subsequence counts; a flagged one means bits that are no code or a code running past the end
     // (eof_sub == nsub, "none", makes the counting kernels take every subsequence: n is already the total)
     if (eof_sub < p.nsub) return fail(c, GHF_E_CORRUPT, "the .crs body does not end on a code boundary");
+  } else if (mode == 2) {
+    if (has_end_mark) *has_end_mark = eof_sub < p.nsub;
+    if (landing) {
+      uint16_t l = 0;
+      GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 5, p.start + p.nsub, 2, hipMemcpyDeviceToHost, c->stream));
+      GHF_HIP(c, hipStreamSynchronize(c->stream));
+      std::memcpy(&l, c->h_u64 + 5, 2);
+      *landing = l == 0xFFFF ? 0 : l;  // 0xFFFF: the last subsequence ended at an end mark (real, or a fake one of a wrong guess)
+    }
   } else if (eof_sub >= p.nsub) {
     return fail(c, GHF_E_CORRUPT, "no end mark in the stream");
   }
@@ -593,10 +609,38 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
   ix.seg_symbols = kSegSymbols;
   ix.n_chunks = n_chunks;
   ix.n_segs = n_segs;
+  ix.flags = (mode == 2 && eof_sub >= p.nsub) ? (uint32_t)GHF_INDEX_NO_END_MARK : 0u;
   if (n) launch_sync_index(p, c->d_seg_abs, n_segs, cl, ix.d_chunk_bit, ix.d_seg_bit, c->stream);
   GHF_HIP(c, hipGetLastError());
   c->fidx_stream = d_stream;
   c->fidx_bytes = stream_bytes;
+  return GHF_OK;
+}
+
+// Multi-GPU decode of a side-car-less stream: one rank's piece.  Rebuilds the piece's side-car and keeps it
+// for the following ghf_decode(index = NULL) of the same (d_piece, piece_bytes).
+int ghf_sync_piece(ghf_ctx* c, const uint8_t* d_piece, size_t piece_bytes, uint32_t first_bit, uint64_t end_bit,
+                   const ghf_code* d_code, uint64_t* landing, uint64_t* n_symbols, int* has_end_mark) {
+  if (!c || !d_piece || !d_code || !landing || !n_symbols || !has_end_mark) return GHF_E_INVAL;
+  if (!aligned16(d_piece)) return fail(c, GHF_E_INVAL, "d_piece must be 16-byte aligned");
+  if (first_bit >= 512 || end_bit > (uint64_t)piece_bytes * 8 || first_bit > end_bit) return fail(c, GHF_E_INVAL, "ghf_sync_piece: bad first_bit / end_bit");
+  GHF_HIP(c, hipSetDevice(c->device));
+  launch_build_decode_tables(d_code, c->d_dt, c->d_status, c->stream);
+  c->fidx_stream = nullptr;
+  *landing = 0;
+  *n_symbols = 0;
+  *has_end_mark = 0;
+  if (end_bit == 0) {  // nothing of this piece is its own
+    c->fidx.n_symbols = 0;
+    c->fidx.n_segs = 0;
+    c->fidx.n_chunks = 0;
+    c->fidx_stream = d_piece;
+    c->fidx_bytes = piece_bytes;
+    return GHF_OK;
+  }
+  const int rc = rebuild_index_at(c, d_piece, piece_bytes, 0, end_bit, 2, (size_t)-1, first_bit, landing, has_end_mark);
+  if (rc) return rc;
+  *n_symbols = c->fidx.n_symbols;
   return GHF_OK;
 }
 
@@ -768,7 +812,7 @@ int ghf_crs_decoded_size(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
     *n_out = 0;
     return GHF_OK;
   }
-  rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, true, (size_t)-1);
+  rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, 1, (size_t)-1);
   if (rc) return rc;
   *n_out = c->fidx.n_symbols;
   return GHF_OK;
@@ -790,7 +834,7 @@ int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int
       return GHF_OK;
     }
     if (c->fidx_stream != d_stream || c->fidx_bytes != stream_bytes) {
-      rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, true, cap);
+      rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, 1, cap);
       if (rc) return rc;
     }
     c->fidx_stream = nullptr;

@@ -100,7 +100,9 @@ struct SyncParams {
   uint64_t stream_bytes;
   uint64_t body_bit0;  // first body bit = 8 * header bytes
   uint64_t end_bit;    // one past the last bit that may belong to a code (8 * stream_bytes for .crs2)
-  uint32_t no_eof;     // .crs: there is no end mark; the last code must end exactly at end_bit
+  uint32_t no_eof;     // 0: .crs2, ends with the end mark.  1: .crs, no end mark, the last code must end exactly at end_bit.
+                       // 2: a piece of a .crs2 (multi-GPU decode): an end mark ends it if there is one, otherwise the last
+                       //    code may run past end_bit and start[nsub] receives by how much
   const DecTables* dt;
   uint64_t nsub;       // 512-bit subsequences covering the body
   uint16_t* start;     // [nsub + 1] current guess: bit offset of the first code boundary inside each subsequence

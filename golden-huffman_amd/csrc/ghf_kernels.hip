@@ -2124,7 +2124,7 @@ __global__ __launch_bounds__(kDecThreads) void k_sync_pass(SyncParams P) {
       }
       // .crs has no end mark: "eof" then means "this cannot be right" -- a bit pattern that is no code, or a last
       // code that runs past the end of the stream
-      if (P.no_eof && pos > limit) eof = true;
+      if (P.no_eof == 1u && pos > limit) eof = true;
       P.cnt[sub] = count;
       P.eof[sub] = eof ? 1 : 0;
       P.used[sub] = (uint16_t)st;
@@ -2135,6 +2135,9 @@ __global__ __launch_bounds__(kDecThreads) void k_sync_pass(SyncParams P) {
           *P.changed = 1;
         }
       }
+      // a PIECE of a stream (mode 2, multi-GPU decode): the last code may run into the next piece's bytes (they are
+      // there as look-ahead); where it ends is the next piece's first code boundary
+      if (P.no_eof == 2u && sub + 1 == P.nsub) P.start[P.nsub] = eof ? (uint16_t)0xFFFF : (uint16_t)(pos - limit);
     }
   }
 }

@@ -100,7 +100,7 @@ EXPORTS = [
     "ghf_write_header", "ghf_header_bytes", "ghf_encode_plan", "ghf_encode_emit", "ghf_compress", "ghf_compress_bound",
     "ghf_chunk_symbols", "ghf_index_alloc", "ghf_index_free", "ghf_parse_header", "ghf_decode", "ghf_decoded_size",
     "ghf_shard_start_bit", "ghf_crs_build_code", "ghf_crs_compress", "ghf_crs_compress_bound", "ghf_crs_parse_header",
-    "ghf_crs_decode", "ghf_crs_decoded_size", "ghf_build_code_ex", "ghf_compress_ex",
+    "ghf_crs_decode", "ghf_crs_decoded_size", "ghf_build_code_ex", "ghf_compress_ex", "ghf_sync_piece",
 ]
 
 _lib = None
@@ -157,6 +157,7 @@ def lib():
     L.ghf_decode.argtypes = [vp, vp, sz, vp, C.POINTER(Index), vp, sz, vp]
     L.ghf_decoded_size.argtypes = [vp, vp, sz, vp, C.POINTER(u64)]
     L.ghf_shard_start_bit.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.ghf_sync_piece.argtypes = [vp, vp, sz, C.c_uint32, u64, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
     L.ghf_build_code_ex.argtypes = [vp, vp, vp, C.c_uint]
     L.ghf_compress_ex.argtypes = [vp, vp, sz, vp, sz, vp, vp, C.POINTER(Index), C.c_uint]
     L.ghf_crs_build_code.argtypes = [vp, vp, vp, vp]
@@ -211,6 +212,7 @@ class Context:
     EMIT_REBASE = EMIT_REBASE
     EMIT_HEADER = EMIT_HEADER
     compress_bound = staticmethod(compress_bound)
+    parse_header = staticmethod(parse_header)
 
     def __init__(self, device=0):
         import torch
@@ -354,6 +356,13 @@ class Context:
                               None if index is None else C.byref(index), d_out.data_ptr(), d_out.numel(), nbytes.data_ptr()),
             "ghf_decode")
         return d_out, nbytes
+
+    def sync_piece(self, d_piece, piece_bytes, first_bit, end_bit, d_code):
+        """one rank's piece of a side-car-less stream (multi-GPU decode): -> (landing, n_symbols, has_end_mark)"""
+        landing, n, eof = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        self._chk(self.L.ghf_sync_piece(self.h, d_piece.data_ptr(), piece_bytes, first_bit, end_bit, d_code.data_ptr(),
+                                        C.byref(landing), C.byref(n), C.byref(eof)), "ghf_sync_piece")
+        return landing.value, n.value, bool(eof.value)
 
     # ---- .crs (SURVEY 8f N3: NormalHuffEncoder / NormalHuffDecoder) ---------------------------
     def new_tree(self):

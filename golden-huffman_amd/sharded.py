@@ -94,3 +94,55 @@ def gather_stream(be, dist, enc, group=None):
     for origin, _, buf in pieces:
         stream[origin : origin + buf.size] |= buf
     return stream
+
+
+def decode_foreign_sharded(be, dist, host_stream, group=None):
+    """Decode a .crs2 that has NO side-car (e.g. one the reference wrote) on all ranks ("per-rank
+    self-sync + one all-gather of symbol counts").  host_stream: the whole file as a numpy uint8 array, the same on
+    every rank (a real deployment would read each rank's byte range only).  The body is cut into world byte ranges;
+    rank g re-synchronises on its piece from a guessed first code boundary, tells rank g+1 where its last code ends,
+    and the guesses are iterated until none moves (Huffman codes self-synchronise: one or two rounds).  Returns
+    (d_out, n_local, out_offset): this rank's decoded bytes, how many, and where they belong in the whole output."""
+    import numpy as np
+
+    torch = be.torch
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    code, hs = be.parse_header(host_stream)
+    d_code = be.code_to_device(code)
+    body = host_stream[hs:]
+    lo, hi = rank * body.size // world, (rank + 1) * body.size // world
+    own = hi - lo
+    piece = np.zeros(((own + 16 + 15) // 16) * 16 + 16, dtype=np.uint8)  # own bytes + look-ahead, zero behind the stream
+    avail = min(body.size, hi + 16) - lo
+    piece[:avail] = body[lo : lo + avail]
+    d_piece = torch.from_numpy(piece).to(be.device)
+    first = 0
+    res = None
+    for _ in range(world + 1):
+        res = be.sync_piece(d_piece, piece.size, first, own * 8, d_code) if own else (0, 0, False)
+        landings = [None] * world
+        dist.all_gather_object(landings, int(res[0]), group=group)
+        new_first = 0 if rank == 0 else landings[rank - 1]
+        moved = [None] * world
+        dist.all_gather_object(moved, int(new_first != first), group=group)
+        first = new_first
+        if not any(moved):
+            break
+    landing, n_local, has_eof = res
+    counts = [None] * world
+    dist.all_gather_object(counts, (int(n_local), bool(has_eof)), group=group)
+    # nothing behind the end mark counts (pieces behind it hold padding / look-ahead only)
+    seen_eof = False
+    offset = 0
+    for g, (cnt, eof) in enumerate(counts):
+        if g == rank:
+            if seen_eof:
+                n_local = 0
+            break
+        if not seen_eof:
+            offset += cnt
+        seen_eof = seen_eof or eof
+    if n_local == 0:
+        return be.empty_u8(1), 0, offset
+    d_out, _ = be.decode(d_piece, piece.size, d_code, None, cap=n_local + 64)  # reuses the side-car sync_piece rebuilt
+    return d_out, n_local, offset

@@ -171,6 +171,19 @@ int ghf_decode(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, const
  * (d_stream, stream_bytes), which then does not repeat the work. */
 int ghf_decoded_size(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code, uint64_t* n_out);
 
+/* Multi-GPU decode of a stream that has no side-car ("per-rank self-sync + one all-gather of symbol
+ * counts"; the reference's decoders, canonical_huff_encoder.cc:377-568, are single-stream).  The caller cuts the body
+ * at byte positions; a rank's piece is its own bytes followed by >= 8 bytes of look-ahead from the next piece (zeros
+ * behind the stream's end).  d_piece / piece_bytes: the piece with its look-ahead; first_bit (< 512): where the first
+ * code boundary of the piece is assumed to be; end_bit = 8 * (own bytes): codes that start at or behind it belong to
+ * the next piece.  Out (host, the call synchronises): landing = how many bits the last code (or the one in progress)
+ * runs past end_bit, i.e. the NEXT piece's first_bit; n_symbols = codes that start in [first_bit, end_bit), up to the
+ * end mark if the piece holds it (has_end_mark).  Because Huffman codes self-synchronise, a wrong first_bit only
+ * spoils the first few symbols; iterate first_bit[g+1] = landing[g] until nothing changes (sharded.py does), then
+ * ghf_decode(d_piece, piece_bytes, d_code, index = NULL, ...) decodes the piece with the side-car this call rebuilt. */
+int ghf_sync_piece(ghf_ctx* ctx, const uint8_t* d_piece, size_t piece_bytes, uint32_t first_bit, uint64_t end_bit,
+                   const ghf_code* d_code, uint64_t* landing, uint64_t* n_symbols, int* has_end_mark);
+
 /* ------------------------------------------------------------------------------------------------
  * inputs on which the reference is undefined because a code would be longer than 32 bits
  * (include/canonical_huff_encoder.h:43-44; needs > 14.9 M bytes with Fibonacci-like counts).  With GHF_CODE_LIMIT

@@ -124,3 +124,59 @@ def test_bench_two_rank_rehearsal():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["parallelism"] == "shard2"
+
+
+def _foreign_worker(rank, world, port, kind, n_total, q):
+    import traceback
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import datagen as dg
+        import pkgload
+        from oracle import oracle as orc
+
+        pkg = pkgload.load()
+        from golden_huffman_amd import sharded
+
+        ctx = pkg.ghf.Context(0)
+        data = dg.make(kind, n_total, seed=12)
+        stream = orc.compress(data)  # byte-identical to what the reference writes: no side-car
+        d_out, n_local, offset = sharded.decode_foreign_sharded(ctx, dist, stream)
+        ctx.sync()
+        q.put((rank, offset, d_out[:n_local].cpu().numpy().tobytes(), ""))
+        dist.barrier()
+        ctx.close()
+    except Exception:
+        q.put((rank, -1, b"", traceback.format_exc()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,n_total,world", [("zipf", (1 << 21) + 5, 2), ("uniform", 1 << 20, 3), ("text", 1500001, 2)])
+def test_foreign_stream_decoded_by_several_ranks_on_one_gpu(kind, n_total, world):
+    """SURVEY 8(e), decode without a side-car: every rank re-synchronises on its byte range of the body (K6 in piece
+    mode), the ranks exchange where their last codes end until nothing moves, symbol counts give the output offsets,
+    and each rank decodes its piece (K7).  Pieces in rank order == the original."""
+    import datagen as dg
+
+    port = 29100 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_foreign_worker, args=(r, world, port, kind, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=200) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(not g[3] for g in got), [g[3] for g in got]
+    data = dg.make(kind, n_total, seed=12)
+    pos = 0
+    for rank, offset, chunk, _ in got:
+        assert offset == pos, (rank, offset, pos)
+        part = np.frombuffer(chunk, dtype=np.uint8)
+        assert np.array_equal(part, data[pos : pos + part.size]), rank
+        pos += part.size
+    assert pos == n_total

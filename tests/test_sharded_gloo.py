@@ -72,6 +72,94 @@ class OracleBackend:
         return torch.tensor([end, (end + 7) // 8 - origin], dtype=torch.int64)
 
 
+    # ---- the side-car-less sharded decode (sharded.decode_foreign_sharded): bit-serial stand-ins for K6 / K7
+    device = "cpu"
+
+    def parse_header(self, host_stream):
+        code, hs = self.orc.parse_header(host_stream)
+        return code, hs
+
+    def code_to_device(self, code):
+        return code
+
+    @staticmethod
+    def _decode_from(piece, code, bit, end_bit, out=None):
+        """decode codes that START in [bit, end_bit); returns (bit behind the last one, count, saw the end mark)"""
+        fc, sp, sym = list(code.first_code), list(code.start_pos), list(code.symbol)
+        n = 0
+        while bit < end_bit:
+            v, l = 0, 0
+            while True:
+                v = (v << 1) | ((int(piece[bit >> 3]) >> (7 - (bit & 7))) & 1)
+                bit += 1
+                l += 1
+                if l >= code.min_len and l <= code.max_len and fc[l] != 1024 and v >= fc[l]:
+                    s = sym[sp[l] + v - fc[l]]
+                    break
+                if l > code.max_len:
+                    return bit, n, True  # garbage of a wrong guess: treat like an end
+            if s == 256:
+                return bit, n, True
+            if out is not None:
+                out.append(s)
+            n += 1
+        return bit, n, False
+
+    def sync_piece(self, d_piece, piece_bytes, first_bit, end_bit, code):
+        self._piece = (d_piece.numpy(), first_bit, end_bit, code)
+        bit, n, eof = self._decode_from(d_piece.numpy(), code, first_bit, end_bit)
+        return (0 if eof else bit - end_bit), n, eof
+
+    def decode(self, d_piece, piece_bytes, code, index, cap=None):
+        piece, first_bit, end_bit, _ = self._piece
+        out = []
+        self._decode_from(piece, code, first_bit, end_bit, out)
+        return torch.tensor(out, dtype=torch.uint8), None
+
+
+def _foreign_worker(rank, world, port, kind, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datagen as dg
+    import pkgload
+
+    pkgload.load()
+    from golden_huffman_amd import sharded
+    from oracle import oracle as orc
+
+    data = dg.make(kind, n_total, seed=6)
+    stream = orc.compress(data)  # what the reference would have written: no side-car
+    d_out, n_local, offset = sharded.decode_foreign_sharded(OracleBackend(), dist, stream)
+    q.put((rank, offset, d_out[:n_local].numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,n_total,world", [("zipf", 20001, 2), ("text", 30000, 3), ("sym16", 9999, 2)])
+def test_foreign_stream_decoded_by_several_ranks(kind, n_total, world):
+    import datagen as dg
+
+    port = 29300 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_foreign_worker, args=(r, world, port, kind, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    data = dg.make(kind, n_total, seed=6)
+    pos = 0
+    for rank, offset, chunk in got:
+        assert offset == pos, (rank, offset, pos)
+        part = np.frombuffer(chunk, dtype=np.uint8)
+        assert np.array_equal(part, data[pos : pos + part.size]), rank
+        pos += part.size
+    assert pos == n_total
+
+
 def _worker(rank, world, port, kind, n_total, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
