@@ -33,6 +33,7 @@ struct ghf_ctx {
   ghf_code* d_code = nullptr;   // scratch tables for ghf_compress
   ghf_tree* d_tree = nullptr;   // scratch tree for ghf_crs_compress
   DecTables* d_dt = nullptr;
+  const ghf_code* dt_code = nullptr;  // ghf_decode_prepare() built d_dt from these tables; consumed by the next ghf_decode
   uint64_t* d_u64 = nullptr;    // [8] scratch scalars: 0 total_bits, 1..2 end, 3 n_symbols, 4 eof_sub, 5 changed
   uint64_t* h_u64 = nullptr;    // [8] pinned mirror
   // K6 workspace (foreign streams)
@@ -288,6 +289,7 @@ int ghf_build_code_ex(ghf_ctx* c, const uint64_t* d_hist, ghf_code* d_code, unsi
   launch_build_code(d_hist, d_code, c->d_status, flags, c->stream);
   GHF_HIP(c, hipGetLastError());
   if (c->plan_code == d_code) c->plan_in = nullptr;  // tables changed: any cached plan is stale
+  if (c->dt_code == d_code) c->dt_code = nullptr;
   return GHF_OK;
 }
 
@@ -626,6 +628,7 @@ int ghf_sync_piece(ghf_ctx* c, const uint8_t* d_piece, size_t piece_bytes, uint3
   if (first_bit >= 512 || end_bit > (uint64_t)piece_bytes * 8 || first_bit > end_bit) return fail(c, GHF_E_INVAL, "ghf_sync_piece: bad first_bit / end_bit");
   GHF_HIP(c, hipSetDevice(c->device));
   launch_build_decode_tables(d_code, c->d_dt, c->d_status, c->stream);
+  c->dt_code = nullptr;
   c->fidx_stream = nullptr;
   *landing = 0;
   *n_symbols = 0;
@@ -649,10 +652,20 @@ int ghf_decoded_size(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, c
   if (!aligned16(d_stream)) return fail(c, GHF_E_INVAL, "d_stream must be 16-byte aligned");
   GHF_HIP(c, hipSetDevice(c->device));
   launch_build_decode_tables(d_code, c->d_dt, c->d_status, c->stream);
+  c->dt_code = nullptr;
   c->fidx_stream = nullptr;
   const int rc = rebuild_index(c, d_stream, stream_bytes, d_code, (size_t)-1);
   if (rc) return rc;
   *n_out = c->fidx.n_symbols;
+  return GHF_OK;
+}
+
+int ghf_decode_prepare(ghf_ctx* c, const ghf_code* d_code) {
+  if (!c || !d_code) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  launch_build_decode_tables(d_code, c->d_dt, c->d_status, c->stream);
+  GHF_HIP(c, hipGetLastError());
+  c->dt_code = d_code;
   return GHF_OK;
 }
 
@@ -661,7 +674,11 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
   if (!c || !d_stream || !d_code || !d_out) return GHF_E_INVAL;
   if (!aligned16(d_stream)) return fail(c, GHF_E_INVAL, "d_stream must be 16-byte aligned");
   GHF_HIP(c, hipSetDevice(c->device));
-  launch_build_decode_tables(d_code, c->d_dt, c->d_status, c->stream);
+  if (c->dt_code == d_code && index) c->dt_code = nullptr;  // prepared: single use (the tables also hold this decode's work counters)
+  else {
+    c->dt_code = nullptr;
+    launch_build_decode_tables(d_code, c->d_dt, c->d_status, c->stream);
+  }
   if (!index) {
     if (c->fidx_stream != d_stream || c->fidx_bytes != stream_bytes) {  // else: ghf_decoded_size already did it
       const int rc = rebuild_index(c, d_stream, stream_bytes, d_code, cap);
@@ -808,6 +825,7 @@ int ghf_crs_decoded_size(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
   int rc = crs_geometry(c, d_tree, stream_bytes, left_bits, &hdr, &end_bit);
   if (rc) return rc;
   launch_crs_decode_tables(d_tree, c->d_dt, c->d_status, c->stream);
+  c->dt_code = nullptr;
   if (end_bit == (uint64_t)hdr * 8) {  // an empty body decodes to nothing
     *n_out = 0;
     return GHF_OK;
@@ -824,6 +842,7 @@ int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int
   if (!aligned16(d_stream)) return fail(c, GHF_E_INVAL, "d_stream must be 16-byte aligned");
   GHF_HIP(c, hipSetDevice(c->device));
   launch_crs_decode_tables(d_tree, c->d_dt, c->d_status, c->stream);
+  c->dt_code = nullptr;
   if (!index) {
     size_t hdr;
     uint64_t end_bit;

@@ -979,12 +979,16 @@ struct PairMode {
   typedef E32 E;
   static constexpr int N = 8;
   static constexpr int kMinWaves = 6;  // <= 80 VGPRs: three 8-wave workgroups per CU (LDS allows exactly three)
+  static constexpr bool kStrided = false;  // one chunk per wave, the grid covers all chunks.  (Measured dead end: the strided
+                                           // loop pushes this variant over its 80 VGPRs, and the build with 6 spilled
+                                           // registers in the tile loop produced wrong streams -- keep it spill-free.)
   static __device__ __forceinline__ bool applies(int max_len) { return max_len <= 16; }
 };
 struct WideMode {
   typedef E64 E;
   static constexpr int N = 16;
   static constexpr int kMinWaves = 4;
+  static constexpr bool kStrided = true;  // small grid, waves stride over the chunks
   static __device__ __forceinline__ bool applies(int max_len) { return max_len > 16; }
 };
 
@@ -1284,11 +1288,17 @@ __global__ __launch_bounds__(kEmitThreads, M::kMinWaves) void k_emit(EmitParams 
   __syncthreads();
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell the compiler it is wave-uniform (SGPR)
-  const uint32_t c = blockIdx.x * kEmitWaves + wave;
-  if (c >= P.nchunks) return;
   const uint64_t start_bit = P.d_start_bit ? *P.d_start_bit : 8ull * (1040ull + 8ull * (uint64_t)max_len);
   const uint64_t origin_byte = (P.flags & GHF_EMIT_REBASE) ? ((start_bit >> 7) << 4) : 0ull;
-  emit_chunk<M>(P, c, tab, stage[wave], start_bit, origin_byte, lane);
+  // one chunk per wave when the grid covers all chunks (PairMode); WideMode is launched with a small grid (it usually
+  // has nothing to do, and an early exit of 1024 workgroups still costs ~5 us of dispatch) and strides over the chunks
+  if constexpr (M::kStrided) {
+    for (uint32_t c = blockIdx.x * kEmitWaves + wave; c < P.nchunks; c += gridDim.x * kEmitWaves)
+      emit_chunk<M>(P, c, tab, stage[wave], start_bit, origin_byte, lane);
+  } else {
+    const uint32_t c = blockIdx.x * kEmitWaves + wave;
+    if (c < P.nchunks) emit_chunk<M>(P, c, tab, stage[wave], start_bit, origin_byte, lane);
+  }
 }
 
 // zero the 16-byte units two chunks share, check the capacity, report where the stream ends
@@ -1348,7 +1358,7 @@ void launch_emit(const EmitParams& p, hipStream_t s) {
   hipLaunchKernelGGL(k_emit_prep, dim3(prep_blocks), dim3(256), 0, s, p);
   const uint32_t blocks = (p.nchunks + kEmitWaves - 1) / kEmitWaves;
   hipLaunchKernelGGL(k_emit<PairMode>, dim3(blocks), dim3(kEmitThreads), 0, s, p);
-  hipLaunchKernelGGL(k_emit<WideMode>, dim3(blocks), dim3(kEmitThreads), 0, s, p);
+  hipLaunchKernelGGL(k_emit<WideMode>, dim3(blocks < 512u ? blocks : 512u), dim3(kEmitThreads), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -100,7 +100,7 @@ EXPORTS = [
     "ghf_write_header", "ghf_header_bytes", "ghf_encode_plan", "ghf_encode_emit", "ghf_compress", "ghf_compress_bound",
     "ghf_chunk_symbols", "ghf_index_alloc", "ghf_index_free", "ghf_parse_header", "ghf_decode", "ghf_decoded_size",
     "ghf_shard_start_bit", "ghf_crs_build_code", "ghf_crs_compress", "ghf_crs_compress_bound", "ghf_crs_parse_header",
-    "ghf_crs_decode", "ghf_crs_decoded_size", "ghf_build_code_ex", "ghf_compress_ex", "ghf_sync_piece",
+    "ghf_crs_decode", "ghf_crs_decoded_size", "ghf_build_code_ex", "ghf_compress_ex", "ghf_sync_piece", "ghf_decode_prepare",
 ]
 
 _lib = None
@@ -157,6 +157,7 @@ def lib():
     L.ghf_decode.argtypes = [vp, vp, sz, vp, C.POINTER(Index), vp, sz, vp]
     L.ghf_decoded_size.argtypes = [vp, vp, sz, vp, C.POINTER(u64)]
     L.ghf_shard_start_bit.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.ghf_decode_prepare.argtypes = [vp, vp]
     L.ghf_sync_piece.argtypes = [vp, vp, sz, C.c_uint32, u64, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
     L.ghf_build_code_ex.argtypes = [vp, vp, vp, C.c_uint]
     L.ghf_compress_ex.argtypes = [vp, vp, sz, vp, sz, vp, vp, C.POINTER(Index), C.c_uint]
@@ -339,6 +340,9 @@ class Context:
                                 d_code.data_ptr(), None if index is None else C.byref(index)),
             "ghf_compress")
         return d_out, nbytes, d_code
+
+    def decode_prepare(self, d_code):
+        self._chk(self.L.ghf_decode_prepare(self.h, d_code.data_ptr()), "ghf_decode_prepare")
 
     def decoded_size(self, d_stream, stream_bytes, d_code):
         n = C.c_uint64(0)

@@ -165,6 +165,13 @@ int ghf_parse_header(const uint8_t* h_stream, size_t n, ghf_code* code, size_t* 
 int ghf_decode(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code,
                const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes);
 
+/* Optional: build the decode tables of d_code ahead of time (one small kernel, k_build_decode_tables) so that the
+ * next ghf_decode(..., d_code, index != NULL, ...) on this context starts with the decode kernel itself -- e.g. on
+ * another stream while the previous buffer is still being emitted.  Single use: the prepared state is consumed by
+ * that ghf_decode and dropped by any other call that rebuilds tables on this context.  The caller orders the two
+ * streams (event) and must not change *d_code in between. */
+int ghf_decode_prepare(ghf_ctx* ctx, const ghf_code* d_code);
+
 /* Size of what a side-car-less stream decodes to (the .crs2 format does not store it: the reference's
  * decoders simply run until the end mark, include/canonical_huff_encoder.cc:404-411).  Rebuilds the
  * side-car on the GPU, synchronises, and keeps it for a following ghf_decode(index = NULL) of the same

@@ -63,7 +63,7 @@ def test_every_stage_matches_reference_fixture(env, golden, name):
     crs = d_out[:nb].cpu().numpy()
     assert nb == g["crs2_bytes"]
     assert sha(crs[: g["header_bytes"]]) == sha(orc.header_bytes(orc.build_code(orc.histogram(data))))
-    assert sha(crs) == g["crs2_sha256"], "first diff at %s" % first_diff(crs, orc.compress(data))
+    assert sha(crs) == g["crs2_sha256"], "first diff at %s" % (first_diff(crs, orc.compress(data)),)
     # K7 with the side-car
     back, nout = ctx.decode(d_out, nb, d_code2, idx)
     ctx.sync()
@@ -438,3 +438,31 @@ def test_foreign_stream_with_a_fixed_length_code(env, k, n):
     out, n2 = ctx.decode(d, ref.size, ctx.code_to_device(code), None, cap=n + 64)
     ctx.sync()
     assert int(n2.item()) == n and np.array_equal(out[:n].cpu().numpy(), data)
+
+
+def test_decode_prepare_is_single_use(env):
+    """ghf_decode_prepare builds the tables ahead of time; the next decode consumes them, the one after rebuilds them
+    (the tables also carry the decode kernel's work counters), and rebuilding the code drops a prepared state."""
+    ghf, ctx, torch = env
+    data = dg.zipf_bytes(700003, seed=31)
+    _, d_out, nb, d_code, idx = run_compress(ghf, ctx, torch, data)
+    for _ in range(2):
+        ctx.decode_prepare(d_code)
+        back, nout = ctx.decode(d_out, nb, d_code, idx)
+        ctx.sync()
+        assert int(nout.item()) == data.size and np.array_equal(back[: data.size].cpu().numpy(), data)
+        back, nout = ctx.decode(d_out, nb, d_code, idx)  # no prepare: must rebuild by itself
+        ctx.sync()
+        assert np.array_equal(back[: data.size].cpu().numpy(), data)
+    # a prepared state does not survive new tables in the same buffer: prepare, rebuild the code from other data,
+    # compress and decode that other data with it
+    ctx.decode_prepare(d_code)
+    other = dg.make("uniform", 300000, seed=2)
+    d_other = to_dev(torch, other)
+    idx2 = ctx.index_alloc(other.size)
+    d_out2, nb2, _ = ctx.compress(d_other, d_code=d_code, index=idx2)
+    back, nout = ctx.decode(d_out2, int(ghf.compress_bound(other.size)), d_code, idx2)
+    ctx.sync()
+    assert int(nout.item()) == other.size and np.array_equal(back[: other.size].cpu().numpy(), other)
+    ctx.index_free(idx2)
+    ctx.index_free(idx)
