@@ -979,9 +979,10 @@ struct PairMode {
   typedef E32 E;
   static constexpr int N = 8;
   static constexpr int kMinWaves = 6;  // <= 80 VGPRs: three 8-wave workgroups per CU (LDS allows exactly three)
-  static constexpr bool kStrided = false;  // one chunk per wave, the grid covers all chunks.  (Measured dead end: the strided
-                                           // loop pushes this variant over its 80 VGPRs, and the build with 6 spilled
-                                           // registers in the tile loop produced wrong streams -- keep it spill-free.)
+  static constexpr bool kStrided = false;  // one chunk per wave, the grid covers all chunks.  (Dead end: with the strided loop
+                                           // the compiler gives up the copy-free A/B register ping-pong (it copies tile
+                                           // registers and spills 6 more) and that build produced wrong streams; not
+                                           // understood, so this variant stays as it is: no copies, no spills.)
   static __device__ __forceinline__ bool applies(int max_len) { return max_len <= 16; }
 };
 struct WideMode {
