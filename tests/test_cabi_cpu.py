@@ -152,3 +152,17 @@ def test_emit_kernels_have_no_scratch():
         assert spill == 0 and priv == 0, (m.group(1), spill, priv)
         seen += 1
     assert seen == 2
+    # K7 may spill (its 128-VGPR budget is tight), but only where it does no harm: every scratch reload must be
+    # followed by a FULL vector-memory wait before any counted one (so nothing is ever inferred from the order in
+    # which a scratch reload and a global load retire)
+    body = text[text.index("_ZN3ghf8k_decodeENS_9DecParamsE:") :]
+    body = body[: body.index(".Lfunc_end")].split("\n")
+    for i, line in enumerate(body):
+        if "scratch_load" in line:
+            for nxt in body[i + 1 : i + 400]:
+                w = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", nxt)
+                if w:
+                    assert w.group(1) == "0", (i, line.strip(), nxt.strip())
+                    break
+            else:
+                raise AssertionError("no vector-memory wait after the reload at line %d" % i)
