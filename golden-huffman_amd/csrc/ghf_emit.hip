@@ -1,0 +1,411 @@
+// golden-huffman_amd/csrc/ghf_emit.hip -- K5, the second pass of the two-pass bit packer (gfx950, wave64).
+//
+// Replaces CanonicalHuffEncoder::encode_file / encode_each_byte and Buffer::write_bits / write_bit / flush_bits
+// (reference include/canonical_huff_encoder.cc:245-285, utils/include/buffer.h:241-248,277-280,290-295) and, when
+// asked to, write_encode_info (canonical_huff_encoder.cc:210-242).  ONE launch, no pre-zeroed output, no global
+// atomics:
+//
+//   * one wave owns one chunk (K4 gave every chunk its start bit) and streams through it 1 KiB at a time; lane l
+//     loads ITS 16 contiguous symbols with one coalesced 16-byte load and looks the 16 codes up in a 32x replicated
+//     LDS table (replica = lane % 32: conflict-free for any data);
+//   * four neighbouring symbols are fused into one item of at most 64 bits (codes <= 16 bits; two symbols for longer
+//     codes), a DPP prefix sum of the items' lengths gives every lane its bit position, and each item is OR-ed into
+//     the wave's LDS bit string as three 32-bit words (ds_or_b32).  No per-lane serial accumulator, no data-dependent
+//     branch: the hot loop is straight-line code;
+//   * completed 16-byte units are copied out coalesced (and their LDS words cleared); the incomplete last unit is
+//     carried to the next tile;
+//   * the 16-byte unit a chunk shares with its predecessor belongs to the LATER chunk: its wave re-encodes the last
+//     symbols of the previous chunk (or takes the header bytes) to fill the bits in front of its own first code, so
+//     every output byte is written exactly once, by one plain store.
+#include "ghf_device.h"
+
+namespace ghf {
+
+constexpr int kEmitTabWords = 256 * 32;  // 32 KiB: [256][32] x u32 (len << 16 | code) or [256][16] x u64 (len << 32 | code)
+
+struct WaveOut {
+  uint32_t* flat;      // the workgroup's whole staging array (every wave ORs through the same base: one address form)
+  uint32_t* st;        // this wave's part of it
+  uint32_t bit0;       // bit index of st[0] inside `flat`
+  uint4* out_units;    // output as 16-byte units
+  uint64_t unit_base;  // unit index (in out) of staging unit 0
+  uint32_t carry;      // valid bits at the front of the staging area (< 128)
+};
+
+// OR the `len` low bits of q (len <= 64, q < 2^len) into the bit string at bit position p (MSB first inside every word)
+__device__ __forceinline__ void deposit64(uint32_t* flat, uint32_t p, uint64_t q, uint32_t len) {
+  const uint64_t V = q << ((64u - len) & 63u);  // left-justified (len == 0: q == 0)
+  const uint32_t hi = (uint32_t)(V >> 32), lo = (uint32_t)V;
+  const uint32_t s = p & 31u;
+  uint32_t* w = flat + (p >> 5);
+  atomicOr(w, hi >> s);
+  atomicOr(w + 1, alignbit(hi, lo, s));
+  atomicOr(w + 2, alignbit(lo, 0u, s));
+}
+
+// One tile: NI items per lane (in stream order) -> bits in the staging area -> whole units to HBM.
+// DRAIN (main loop only): right before the first global store of the tile, wait until at most ONE vector-memory
+// operation is outstanding.  In program order the outstanding ones are: the load of tile t+1 (issued two tiles ago),
+// the stores of tile t-1, the load of tile t+2 (issued when this tile started) -- so this guarantees tile t+1's data
+// and retires the old stores while tile t+2 stays in flight, and the compiler derives no wait of its own from a
+// store count it would have to guess.
+template <int NI, bool DRAIN>
+__device__ __forceinline__ uint32_t emit_items(WaveOut& W, const uint64_t (&q)[NI], const uint32_t (&l)[NI], int lane,
+                                               uint32_t* seg_dst, uint32_t seg_base) {
+  uint32_t T = 0;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) T += l[i];
+  const uint32_t incl = wave_incl_scan_u32(T);
+  const uint32_t excl = incl - T;
+  const uint32_t total = wave_last_u32(incl);
+  uint32_t p = W.bit0 + W.carry + excl;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    deposit64(W.flat, p, q[i], l[i]);
+    p += l[i];
+  }
+  wave_sync();
+  const uint32_t endbits = W.carry + total;
+  const uint32_t U = endbits >> 7;  // <= 128
+  if (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F71);  // vmcnt(1)
+  if (seg_dst) *seg_dst = seg_base + excl;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t j = (uint32_t)lane + 64u * h;
+    if (j < U) {
+      uint4* su = reinterpret_cast<uint4*>(W.st) + j;
+      uint4 v = *su;
+      *su = make_uint4(0, 0, 0, 0);
+      v.x = bswap32(v.x); v.y = bswap32(v.y); v.z = bswap32(v.z); v.w = bswap32(v.w);
+      W.out_units[W.unit_base + j] = v;
+    }
+  }
+  wave_sync();
+  if (U) {  // the incomplete unit moves to the front
+    if (lane < 4) {
+      const uint32_t t = W.st[4 * U + lane];
+      W.st[4 * U + lane] = 0;
+      W.st[lane] = t;
+    }
+    W.unit_base += U;
+  }
+  W.carry = endbits & 127u;
+  wave_sync();
+  return total;
+}
+
+// ---- table entries ----
+// codes <= 16 bits: u32 = len << 16 | code, 32 replicas; a lane's four-symbol item comes from one input dword
+__device__ __forceinline__ void items_narrow(const uint32_t* tab, uint32_t r, const uint4& v, uint32_t cnt, uint64_t (&q)[4],
+                                             uint32_t (&l)[4]) {
+  const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint32_t e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t b = (vv[k] >> (8 * j)) & 0xFFu;
+      e[j] = tab[(b << 5) | r];
+      if ((uint32_t)(4 * k + j) >= cnt) e[j] = 0;  // folds away for cnt == 16
+    }
+    const uint32_t l1 = e[1] >> 16, l3 = e[3] >> 16;
+    const uint32_t p0 = ((e[0] & 0xFFFFu) << l1) | (e[1] & 0xFFFFu);
+    const uint32_t p1 = ((e[2] & 0xFFFFu) << l3) | (e[3] & 0xFFFFu);
+    const uint32_t lp1 = (e[2] >> 16) + l3;
+    q[k] = ((uint64_t)p0 << lp1) | p1;
+    l[k] = (e[0] >> 16) + l1 + lp1;
+  }
+}
+
+// codes up to 32 bits: u64 = len << 32 | code, 16 replicas; two symbols per item
+__device__ __forceinline__ void items_wide(const uint64_t* tab, uint32_t r, const uint4& v, uint32_t cnt, uint64_t (&q)[8],
+                                           uint32_t (&l)[8]) {
+  const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const uint32_t b0 = (vv[p >> 1] >> (16 * (p & 1))) & 0xFFu, b1 = (vv[p >> 1] >> (16 * (p & 1) + 8)) & 0xFFu;
+    uint64_t e0 = tab[(b0 << 4) | r], e1 = tab[(b1 << 4) | r];
+    if ((uint32_t)(2 * p) >= cnt) e0 = 0;
+    if ((uint32_t)(2 * p + 1) >= cnt) e1 = 0;
+    const uint32_t l1 = (uint32_t)(e1 >> 32);
+    q[p] = ((uint64_t)(uint32_t)e0 << l1) | (uint64_t)(uint32_t)e1;
+    l[p] = (uint32_t)(e0 >> 32) + l1;
+  }
+}
+
+template <bool WIDE>
+struct EmitMode;
+template <>
+struct EmitMode<false> {
+  static constexpr int NI = 4;
+  static __device__ __forceinline__ void items(const uint32_t* tab, int lane, const uint4& v, uint32_t cnt, uint64_t (&q)[4],
+                                               uint32_t (&l)[4]) {
+    items_narrow(tab, (uint32_t)lane & 31u, v, cnt, q, l);
+  }
+  static __device__ __forceinline__ void one(const uint32_t* tab, int lane, uint32_t byte, uint32_t& code, uint32_t& len) {
+    const uint32_t e = tab[(byte << 5) | ((uint32_t)lane & 31u)];
+    code = e & 0xFFFFu;
+    len = e >> 16;
+  }
+};
+template <>
+struct EmitMode<true> {
+  static constexpr int NI = 8;
+  static __device__ __forceinline__ void items(const uint32_t* tab, int lane, const uint4& v, uint32_t cnt, uint64_t (&q)[8],
+                                               uint32_t (&l)[8]) {
+    items_wide(reinterpret_cast<const uint64_t*>(tab), (uint32_t)lane & 15u, v, cnt, q, l);
+  }
+  static __device__ __forceinline__ void one(const uint32_t* tab, int lane, uint32_t byte, uint32_t& code, uint32_t& len) {
+    const uint64_t e = reinterpret_cast<const uint64_t*>(tab)[(byte << 4) | ((uint32_t)lane & 15u)];
+    code = (uint32_t)e;
+    len = (uint32_t)(e >> 32);
+  }
+};
+
+// A tile's items -> output.  Codes <= 16 bits: one pass (<= 127 + 1024 * 16 bits fit the staging area).  Longer codes:
+// the two half-waves one after the other, each at most 32 lanes x 512 bits.
+template <bool WIDE, bool DRAIN>
+__device__ __forceinline__ uint32_t emit_tile(WaveOut& W, const uint64_t (&q)[EmitMode<WIDE>::NI],
+                                              const uint32_t (&l)[EmitMode<WIDE>::NI], int lane, uint32_t* seg_out,
+                                              bool seg_valid, uint32_t relbits) {
+  constexpr int NI = EmitMode<WIDE>::NI;
+  uint32_t* const seg_dst = (seg_out && seg_valid && (lane & 3) == 0) ? seg_out : nullptr;  // stored with the tile's units
+  if (!WIDE) {
+    return emit_items<NI, DRAIN>(W, q, l, lane, seg_dst, relbits);
+  } else {
+    uint32_t total = 0;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const bool mine = (lane >> 5) == h;
+      uint64_t qq[NI];
+      uint32_t ll[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        qq[i] = mine ? q[i] : 0ull;
+        ll[i] = mine ? l[i] : 0u;
+      }
+      total += emit_items<NI, false>(W, qq, ll, lane, mine ? seg_dst : nullptr, relbits + total);
+    }
+    return total;
+  }
+}
+
+struct EmitGeom {      // wave-uniform facts about the stream
+  uint64_t start_bit;  // stream bit of this buffer's first code
+  uint64_t origin_byte;  // stream byte that d_out[0] stands for (GHF_EMIT_REBASE), else 0
+  int max_len;
+};
+
+template <bool WIDE>
+__device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& G, uint32_t c, const uint32_t* tab,
+                                           uint32_t* flat, uint32_t* st, int lane) {
+  typedef EmitMode<WIDE> M;
+  constexpr int NI = M::NI;
+  const uint64_t chunk = 1ull << P.chunk_log2;
+  const uint64_t sym0 = (uint64_t)c << P.chunk_log2;
+  const uint64_t nsym = (P.n - sym0 < chunk) ? (P.n - sym0) : chunk;
+  const uint8_t* pin = P.in + sym0;
+  const bool aligned = (((uintptr_t)pin) & 15u) == 0;
+  const uint64_t Pc = G.start_bit + P.chunk_off[c];
+  WaveOut W;
+  W.flat = flat;
+  W.st = st;
+  W.bit0 = (uint32_t)(st - flat) * 32u;
+  W.out_units = reinterpret_cast<uint4*>(P.out);
+  W.unit_base = (Pc >> 7) - (G.origin_byte >> 4);
+  W.carry = (uint32_t)(Pc & 127u);
+  for (int i = lane; i < kStageWords / 4; i += 64) reinterpret_cast<uint4*>(st)[i] = make_uint4(0, 0, 0, 0);
+  if (lane == 0 && P.chunk_bit) P.chunk_bit[c] = Pc - G.origin_byte * 8;  // relative to d_out[0]
+  wave_sync();
+
+  // ---- the bits in front of this chunk's first code that share its first 16-byte unit
+  if (W.carry) {
+    if (c > 0) {
+      // the previous chunk's last 128 symbols (it is a full chunk, >= 4096 symbols), two per lane: a code has at least
+      // one bit, so they cover the <= 127 bits wanted
+      const uint8_t* pp = pin - 128 + 2 * lane;
+      uint32_t c0, l0, c1, l1;
+      M::one(tab, lane, pp[0], c0, l0);
+      M::one(tab, lane, pp[1], c1, l1);
+      uint64_t pr = ((uint64_t)c0 << l1) | c1;
+      uint32_t lp = l0 + l1;
+      const uint32_t incl = wave_incl_scan_u32(lp);
+      const uint32_t after = wave_last_u32(incl) - incl;     // bits of the lanes behind me
+      const int end = (int)W.carry - (int)after;             // my pair ends here (staging bits)
+      int start = end - (int)lp;
+      if (end > 0) {
+        if (start < 0) {  // only the pair's last `end` bits are inside the unit
+          lp = (uint32_t)end;
+          pr &= ~0ull >> (64u - lp);
+          start = 0;
+        }
+        deposit64(flat, W.bit0 + (uint32_t)start, pr, lp);
+      }
+    } else if (!(P.flags & GHF_EMIT_REBASE)) {
+      // chunk 0 of a buffer that starts at stream byte 0: bytes in front of the first code stay (the .crs2 header's
+      // last words, or whatever the caller put there); a5 writes them here when it rides along
+      if (lane < 4) {
+        const int bits_before = (int)W.carry - 32 * lane;
+        if (bits_before > 0) {
+          const uint64_t gw = (Pc >> 7) * 4 + (uint64_t)lane;
+          uint32_t word;
+          if (P.flags & GHF_EMIT_HEADER) word = header_word(P.code, (int)gw, G.max_len);
+          else word = bswap32(reinterpret_cast<const uint32_t*>(P.out)[gw]);
+          st[lane] = bits_before >= 32 ? word : (word & (~0u << (32 - bits_before)));
+        }
+      }
+    }
+    wave_sync();
+  }
+  if (c == 0 && (P.flags & GHF_EMIT_HEADER)) {
+    // a5, canonical_huff_encoder.cc:210-242: the header words in front of the first unit that holds code bits
+    const int nwords = 1 + GHF_NSYM + 2 + 2 * G.max_len;
+    const uint64_t first_unit_word = (Pc >> 7) * 4;
+    for (int w = lane; w < nwords && (uint64_t)w < first_unit_word; w += 64)
+      reinterpret_cast<uint32_t*>(P.out)[w] = bswap32(header_word(P.code, w, G.max_len));
+  }
+
+  uint32_t relbits = 0;  // bits of this chunk emitted so far (a chunk has at most 2^20 symbols of <= 32 bits)
+  const uint64_t nfull = aligned ? (nsym / kSymPerIter) : 0;
+  const uint4* pv = reinterpret_cast<const uint4*>(pin) + lane;
+  uint32_t* const segp = P.seg_bit ? P.seg_bit + ((sym0 + (uint64_t)lane * 16) >> 6) : nullptr;
+  uint64_t it = 0;
+  // ---- full 1 KiB tiles, two per trip.  While tile `it` is packed, the loads of tiles it+1 and it+2 are in flight;
+  //      A and B are each re-loaded right after they were consumed, so no register ever has to be copied while
+  //      its load is pending (the last prefetches are clamped to the last full tile and simply unused).
+  //      (Codes beyond 16 bits take the plain loop below: rare, and it keeps that instantiation free of spills.)
+  if (!WIDE && nfull >= 2) {
+    uint4 A = pv[0], B = pv[64];
+    __builtin_amdgcn_s_waitcnt(0x0F71);  // vmcnt(1): A has arrived, so the loop is entered in the state its back edge leaves
+    for (; it + 1 < nfull; it += 2) {
+      {
+        const uint4 v = A;
+        const uint64_t nx = (it + 2 < nfull) ? it + 2 : nfull - 1;
+        A = pv[nx * 64];
+        uint64_t q[NI];
+        uint32_t l[NI];
+        M::items(tab, lane, v, 16, q, l);
+        relbits += emit_tile<WIDE, !WIDE>(W, q, l, lane, segp ? segp + it * 16 : nullptr, true, relbits);
+      }
+      {
+        const uint4 v = B;
+        const uint64_t nx = (it + 3 < nfull) ? it + 3 : nfull - 1;
+        B = pv[nx * 64];
+        uint64_t q[NI];
+        uint32_t l[NI];
+        M::items(tab, lane, v, 16, q, l);
+        relbits += emit_tile<WIDE, !WIDE>(W, q, l, lane, segp ? segp + (it + 1) * 16 : nullptr, true, relbits);
+      }
+    }
+  }
+  // ---- whatever is left: an odd full tile, the ragged tail, unaligned input, and -- on the stream's last chunk --
+  //      one extra pass for the end mark and the padding (canonical_huff_encoder.cc:255-257, buffer.h:277-280)
+  const uint64_t niter = (nsym + kSymPerIter - 1) / kSymPerIter;
+  const bool last = (P.flags & GHF_EMIT_LAST) && c + 1 == P.nchunks;
+  const uint64_t nsteps = niter + (last ? 1 : 0);
+#pragma unroll 1
+  for (; it < nsteps; ++it) {
+    uint64_t q[NI];
+    uint32_t l[NI];
+    bool seg_valid = false;
+    uint32_t* seg_out = nullptr;
+    if (it < niter) {
+      const uint64_t sb = it * kSymPerIter;
+      const uint64_t rem = nsym - sb;
+      uint4 v;
+      uint32_t cnt = 16;
+      if (aligned && rem >= (uint64_t)kSymPerIter) {
+        v = pv[it * 64];
+      } else {  // byte loads, never past the end of the buffer
+        const uint64_t lo = (uint64_t)lane * 16;
+        cnt = rem > lo ? (rem - lo >= 16 ? 16u : (uint32_t)(rem - lo)) : 0u;
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t j = 0; j < cnt; ++j) w[j >> 2] |= (uint32_t)pin[sb + lo + j] << (8 * (j & 3));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      M::items(tab, lane, v, cnt, q, l);
+      seg_valid = cnt != 0;
+      seg_out = segp ? segp + it * 16 : nullptr;
+    } else {
+      const uint32_t el = P.code->length[GHF_NSYM - 1], ec = P.code->codeword[GHF_NSYM - 1];
+      const uint32_t pad = (uint32_t)((0 - (Pc + relbits + el)) & 7u);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        q[i] = 0;
+        l[i] = 0;
+      }
+      if (lane == 0) {
+        q[0] = ((uint64_t)ec << pad) | ((1u << pad) - 1u);
+        l[0] = el + pad;
+      }
+    }
+    relbits += emit_tile<WIDE, false>(W, q, l, lane, seg_out, seg_valid, relbits);
+  }
+  // the chunk's last, incomplete unit belongs to the next chunk's wave -- unless this is the buffer's last chunk
+  if (c + 1 == P.nchunks && W.carry && lane == 0) {
+    uint4 v = *reinterpret_cast<const uint4*>(st);
+    v.x = bswap32(v.x); v.y = bswap32(v.y); v.z = bswap32(v.z); v.w = bswap32(v.w);
+    W.out_units[W.unit_base] = v;
+  }
+}
+
+__global__ __launch_bounds__(kEmitThreads, 6) void k_emit(EmitParams P) {
+  __shared__ __attribute__((aligned(16))) uint32_t tab[kEmitTabWords];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kEmitWaves * kStageWords];
+  __shared__ int status0;
+  const int tid = threadIdx.x;
+  if (tid == 0) status0 = *P.status;  // a previous stage failed -> uniform exit
+  __syncthreads();
+  if (status0 != 0) return;
+  EmitGeom G;
+  G.max_len = P.code->max_len;
+  G.start_bit = P.d_start_bit ? *P.d_start_bit : 8ull * (1040ull + 8ull * (uint64_t)G.max_len);
+  G.origin_byte = (P.flags & GHF_EMIT_REBASE) ? ((G.start_bit >> 7) << 4) : 0ull;
+  // where the stream ends; does it fit?  (every workgroup computes the same answer from the same few words)
+  uint64_t end = G.start_bit + P.chunk_off[P.nchunks];
+  if (P.flags & GHF_EMIT_LAST) {
+    end += P.code->length[GHF_NSYM - 1];
+    end = (end + 7) & ~7ull;
+  }
+  const uint64_t end_byte = ((end + 7) >> 3) - G.origin_byte;
+  const uint64_t end_unit_bytes = (((end >> 7) + 1) << 4) - G.origin_byte;  // through the unit holding the end bit
+  const bool fits = end_unit_bytes <= P.cap || (((end & 127u) == 0) && end_byte <= P.cap);
+  if (blockIdx.x == 0 && tid == 0) {
+    if (!fits) latch_status(P.status, GHF_E_CAP);
+    if (P.d_end) {
+      P.d_end[0] = end;
+      P.d_end[1] = end_byte;
+    }
+  }
+  if (!fits) return;
+  const bool wide = G.max_len > 16;
+  {
+    // thread -> symbol tid / 2, replicas 16 * (tid & 1) ..  (u32) or 8 * (tid & 1) .. (u64): 64 bytes each
+    const int s = tid >> 1;
+    const uint32_t code = P.code->codeword[s], len = P.code->length[s];
+    uint4 v;
+    if (!wide) {
+      const uint32_t e = (len << 16) | (code & 0xFFFFu);
+      v = make_uint4(e, e, e, e);
+    } else {
+      v = make_uint4(code, len, code, len);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(tab) + (s * 8 + (tid & 1) * 4);
+    dst[0] = v; dst[1] = v; dst[2] = v; dst[3] = v;
+  }
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell the compiler it is wave-uniform (SGPR)
+  const uint32_t c = blockIdx.x * kEmitWaves + wave;
+  if (c >= P.nchunks) return;
+  if (!wide) emit_chunk<false>(P, G, c, tab, stage, stage + wave * kStageWords, lane);
+  else emit_chunk<true>(P, G, c, tab, stage, stage + wave * kStageWords, lane);
+}
+
+void launch_emit(const EmitParams& p, hipStream_t s) {
+  const uint32_t blocks = (p.nchunks + kEmitWaves - 1) / kEmitWaves;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(kEmitThreads), 0, s, p);
+}
+
+}  // namespace ghf

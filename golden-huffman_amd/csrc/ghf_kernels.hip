@@ -6,42 +6,13 @@
 //   K3  (same kernel)      canonical assignment                     (canonical_huff_encoder.cc:69-141,289-345)
 //   a5  k_write_header     big-endian .crs2 header                  (canonical_huff_encoder.cc:210-242)
 //   K4  k_chunk_bits/k_scan per-chunk bit totals + exclusive scan   (first pass of the two-pass packer)
-//   K5  k_emit             MSB-first bit packing, one wave per chunk (canonical_huff_encoder.cc:245-285,
-//                                                                     buffer.h:241-248,277-280,290-295)
+//   K5  (ghf_emit.hip)
 //   K7  k_decode           table-driven block-parallel decode        (canonical_huff_encoder.cc:377-568)
 //
 // File:line citations are relative to the reference tree (chenghuige/golden-huffman).
-#include "ghf_internal.h"
+#include "ghf_device.h"
 
 namespace ghf {
-
-// ------------------------------------------------------------------------------------------------
-// small helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
-
-// LDS traffic between the lanes of ONE wave needs no s_barrier: the LDS executes a wave's
-// instructions in order.  This only stops the compiler from moving LDS accesses across the point.
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-__device__ __forceinline__ void latch_status(int* st, int code) { atomicCAS(st, 0, code); }
-
-// inclusive prefix sum over the 64 lanes in six v_add_u32_dpp: row_shr 1/2/4/8 inside the rows of 16, then
-// row_bcast:15 and row_bcast:31 carry the row totals across (the classic gfx9 wave64 scan; no LDS traffic,
-// unlike __shfl_up, which lowers to ds_bpermute_b32 and costs an LDS round trip per step)
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int /*lane*/) {
-  int x = (int)v;
-  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
-  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
-  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
-  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
-  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1 and 3
-  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2 and 3
-  return (uint32_t)x;
-}
 
 // ------------------------------------------------------------------------------------------------
 // K1: histogram.  bins[256][32] in LDS, replica = lane % 32: in every 32-lane LDS group each lane
@@ -592,7 +563,7 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
   const uint32_t num = (lane >= 1 && lane <= max_len) ? cl.num[lane] : 0u;
   const unsigned long long nzmask = __ballot(num != 0);
   const int min_len = __ffsll((long long)nzmask) - 1;                 // .cc:93-98
-  const uint32_t spos = wave_incl_scan_u32(num, lane) - num;          // .cc:104-105 start_pos[i] = sum num[1..i-1]
+  const uint32_t spos = wave_incl_scan_u32(num) - num;          // .cc:104-105 start_pos[i] = sum num[1..i-1]
   if (lane >= 1 && lane <= max_len) cl.start_pos[lane] = spos;
   if (lane == 0) {                                                     // .cc:109-121
     uint32_t fc = 0;
@@ -801,16 +772,6 @@ void launch_crs_finish(const ghf_tree* d_tree, const uint64_t* d_total_bits, uin
 // a5: header.  u32 big-endian: 257, symbol_[0..256], min_len, max_len, (start_pos[i], first_code[i]) i=1..max_len
 // (canonical_huff_encoder.cc:223-237, utils/include/buffer.h:261-268)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t header_word(const ghf_code* code, int w, int max_len) {
-  if (w == 0) return GHF_NSYM;
-  if (w <= GHF_NSYM) return code->symbol[w - 1];
-  if (w == GHF_NSYM + 1) return (uint32_t)code->min_len;
-  if (w == GHF_NSYM + 2) return (uint32_t)max_len;
-  const int k = w - (GHF_NSYM + 3);
-  const int i = 1 + (k >> 1);
-  return (k & 1) ? code->first_code[i] : code->start_pos[i];
-}
-
 __global__ __launch_bounds__(256) void k_write_header(const ghf_code* __restrict__ code, uint8_t* __restrict__ out,
                                                       uint64_t cap, int* __restrict__ status) {
   const int max_len = code->max_len;
@@ -940,426 +901,6 @@ void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t 
     hipLaunchKernelGGL(k_chunk_bits_direct, dim3(blocks), dim3(256), 0, s, d_in, n, chunk_log2, nchunks, d_code,
                        d_chunk_off);
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_chunk_off, nchunks, d_total_bits);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K5: emit.  One wave owns one chunk and streams through it 1 KiB at a time:
-//   lane l loads ITS 16 contiguous symbols with one coalesced 16-B load, looks the 16 codes up in a
-//   32x replicated LDS table (conflict-free), a wave prefix sum of the 16-symbol bit totals gives
-//   the lane its bit offset, the lane packs MSB-first into a 64-bit accumulator and stores whole
-//   32-bit words into the wave's LDS staging area; the partial last word of every lane is OR-ed in
-//   afterwards (the neighbour's plain store left zeros there).  Completed 16-byte units are written
-//   to HBM coalesced; the incomplete unit is carried to the next iteration.  Only the first and the
-//   last unit of a chunk are shared with a neighbouring chunk: those are OR-ed into pre-zeroed
-//   memory (k_emit_prep).  No workgroup barrier after the table is built.
-// ------------------------------------------------------------------------------------------------
-struct E32 {  // table entry for codes <= 24 bits: code << 8 | len
-  typedef uint32_t T;
-  static __device__ __forceinline__ T make(uint32_t code, uint32_t len) { return (code << 8) | len; }
-  static __device__ __forceinline__ uint32_t len(T e) { return e & 0xFFu; }
-  static __device__ __forceinline__ uint32_t code(T e) { return e >> 8; }
-  static __device__ __forceinline__ uint32_t slot(uint32_t byte, uint32_t lane) { return (byte << 5) | (lane & 31u); }
-  static constexpr uint32_t kRep = 32;
-};
-struct E64 {  // codes up to 32 bits
-  typedef uint64_t T;
-  static __device__ __forceinline__ T make(uint32_t code, uint32_t len) { return ((uint64_t)len << 32) | code; }
-  static __device__ __forceinline__ uint32_t len(T e) { return (uint32_t)(e >> 32); }
-  static __device__ __forceinline__ uint32_t code(T e) { return (uint32_t)e; }
-  static __device__ __forceinline__ uint32_t slot(uint32_t byte, uint32_t lane) { return (byte << 4) | (lane & 15u); }
-  static constexpr uint32_t kRep = 16;
-};
-
-// Two variants of the same kernel, picked by max_len (device side: the host cannot know it without a round trip;
-// both are launched, the one that does not apply exits at once):
-//   PairMode  max_len <= 16 : two neighbouring symbols are fused into one <= 32-bit item right after the table
-//                             lookup, which halves the serial work of the bit packer (every BASELINE config)
-//   WideMode  17..32        : one item per symbol, 64-bit table entries
-struct PairMode {
-  typedef E32 E;
-  static constexpr int N = 8;
-  static constexpr int kMinWaves = 6;  // <= 80 VGPRs: three 8-wave workgroups per CU (LDS allows exactly three)
-  static constexpr bool kStrided = false;  // one chunk per wave, the grid covers all chunks.  (Dead end: with the strided loop
-                                           // the compiler gives up the copy-free A/B register ping-pong (it copies tile
-                                           // registers and spills 6 more) and that build produced wrong streams; not
-                                           // understood, so this variant stays as it is: no copies, no spills.)
-  static __device__ __forceinline__ bool applies(int max_len) { return max_len <= 16; }
-};
-struct WideMode {
-  typedef E64 E;
-  static constexpr int N = 16;
-  static constexpr int kMinWaves = 4;
-  static constexpr bool kStrided = true;  // small grid, waves stride over the chunks
-  static __device__ __forceinline__ bool applies(int max_len) { return max_len > 16; }
-};
-
-template <int N>
-struct Items {  // what one lane appends in one iteration: N (code, length <= 32) pairs, in stream order
-  uint32_t code[N];
-  uint32_t len[N];
-};
-
-template <typename M>
-__device__ __forceinline__ void make_items(const typename M::E::T (&e)[16], Items<M::N>& it) {
-  typedef typename M::E E;
-  if (M::N == 16) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      it.code[j & (M::N - 1)] = E::code(e[j]);
-      it.len[j & (M::N - 1)] = E::len(e[j]);
-    }
-  } else {
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const uint32_t l1 = E::len(e[2 * p + 1]);
-      it.code[p & (M::N - 1)] = (E::code(e[2 * p]) << l1) | E::code(e[2 * p + 1]);
-      it.len[p & (M::N - 1)] = E::len(e[2 * p]) + l1;
-    }
-  }
-}
-
-struct WaveOut {
-  uint32_t* st;         // this wave's LDS staging words
-  uint4* out_units;     // output as 16-byte units
-  uint64_t unit_base;   // unit index (in out) of staging unit 0
-  uint32_t carry;       // valid bits at the front of the staging area (< 128)
-  uint32_t cw;          // the staging word holding the last carried bits (top carry%32 bits valid, rest zero)
-  bool first_pending;   // the chunk's first unit has not been written yet -> it is shared -> OR it in
-};
-
-__device__ __forceinline__ void or_unit_words(uint4* unit, const uint32_t* st4, int lane) {
-  if (lane < 4) {
-    const uint32_t v = st4[lane];
-    if (v) atomicOr(reinterpret_cast<unsigned int*>(unit) + lane, bswap32(v));
-  }
-}
-
-// pack this lane's items at staging bit `sb`; lanes with active == false do nothing.
-// pass_total = bits of all active lanes; is_first_lane marks the lowest active lane.
-// DRAIN (main loop only): right before the first global store of the tile, wait until at most ONE vector-memory
-// operation is outstanding.  In program order the outstanding ones are: the load of tile t+1 (issued two tiles ago),
-// the stores of tile t-1, the load of tile t+2 (issued when this tile started) -- so this guarantees tile t+1's data
-// and retires the old stores while tile t+2 stays in flight.  Without it the compiler has to derive its waits from
-// a store count it cannot know (the copy-out is a loop) and falls back to waiting for (almost) everything, i.e. for
-// this tile's own stores, before the next tile may touch its input.
-template <int N, bool DRAIN>
-__device__ __forceinline__ void pack_pass(WaveOut& W, const Items<N>& it, bool active, uint32_t sb, uint32_t pass_total,
-                                          bool is_first_lane, int lane, uint32_t* seg_out, uint32_t seg_val) {
-  uint32_t* st = W.st;
-  uint32_t w = sb >> 5;
-  uint32_t nb = sb & 31u;
-  uint64_t acc = 0;
-  // the word that will only receive OR-ed residuals (and the rest of its unit) must start as zero
-  if (is_first_lane) {
-    const uint32_t wpart = (W.carry + pass_total) >> 5;
-    st[wpart] = 0; st[wpart + 1] = 0; st[wpart + 2] = 0; st[wpart + 3] = 0;
-  }
-  wave_sync();
-  if (active) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const uint32_t l = it.len[j];
-      acc = (acc << l) | it.code[j];
-      nb += l;
-      if (nb >= 32u) {
-        nb -= 32u;
-#if defined(GHF_EXP) && GHF_EXP == 6
-        w++;
-#else
-        st[w++] = (uint32_t)(acc >> nb);
-#endif
-      }
-    }
-  }
-  wave_sync();
-  if (active && nb) atomicOr(&st[w], ((uint32_t)acc) << (32u - nb));
-  // the first lane's first word was stored with zeros where the carried bits of the previous pass were (or was
-  // just cleared above): put them back.  W.cw was read at the end of the previous pass, so nobody waits for it.
-  if (is_first_lane && (sb & 31u)) atomicOr(&st[sb >> 5], W.cw);
-  wave_sync();
-  // write the completed 16-byte units, carry the incomplete one
-  const uint32_t endbits = W.carry + pass_total;
-  const uint32_t U = endbits >> 7;
-  if (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F71);  // vmcnt(1)
-  if (seg_out) *seg_out = seg_val;
-  for (uint32_t j = lane; j < U; j += 64) {
-    uint4 v = *reinterpret_cast<const uint4*>(&st[4 * j]);
-    v.x = bswap32(v.x); v.y = bswap32(v.y); v.z = bswap32(v.z); v.w = bswap32(v.w);
-    uint4* dst = W.out_units + (W.unit_base + j);
-    if (j == 0 && W.first_pending) {
-      unsigned int* d = reinterpret_cast<unsigned int*>(dst);
-      if (v.x) atomicOr(d + 0, v.x);
-      if (v.y) atomicOr(d + 1, v.y);
-      if (v.z) atomicOr(d + 2, v.z);
-      if (v.w) atomicOr(d + 3, v.w);
-    } else {
-#if defined(GHF_EXP) && GHF_EXP == 5
-      if (v.x == 0x12345678u && v.y == 0x9abcdef0u) *dst = v;
-#else
-      *dst = v;
-#endif
-    }
-  }
-  wave_sync();
-  if (U) {
-    if (lane < 4) {
-      const uint32_t t = st[4 * U + lane];
-      st[lane] = t;
-    }
-    W.unit_base += U;
-    W.first_pending = false;
-  }
-  W.carry = endbits & 127u;
-  wave_sync();
-  W.cw = st[W.carry >> 5];
-}
-
-// one wave iteration: items of every lane -> bits in the staging area -> whole units to HBM
-template <int N, bool DRAIN>
-__device__ __forceinline__ void emit_iteration(WaveOut& W, const Items<N>& it, int lane, uint32_t* seg_out, uint64_t relbits,
-                                               bool seg_valid, uint32_t& total_out) {
-  uint32_t T = 0;
-#pragma unroll
-  for (int j = 0; j < N; ++j) T += it.len[j];
-  const uint32_t incl = wave_incl_scan_u32(T, lane);
-  const uint32_t excl = incl - T;
-  const uint32_t total = __shfl(incl, 63, 64);
-  total_out = total;
-  uint32_t* const seg_dst = (seg_out && seg_valid && (lane & 3) == 0) ? seg_out : nullptr;  // stored with the tile's units
-  // normally one pass; only with long codes (> 16 bits on average) the 1024 symbols are packed as two half-waves,
-  // each at most 512 x 32 bits, so the staging area never overflows
-  const bool split = W.carry + total + 128u > (uint32_t)kStageCapBits;
-  const uint32_t half_total = __shfl(incl, 31, 64);
-  const int npass = split ? 2 : 1;
-  for (int p = 0; p < npass; ++p) {
-    const bool second = p == 1;
-    const bool active = !split || ((lane >= 32) == second);
-    const uint32_t base = second ? half_total : 0u;
-    const uint32_t ptotal = split ? (second ? total - half_total : half_total) : total;
-    pack_pass<N, DRAIN>(W, it, active, W.carry + (excl - base), ptotal, lane == (second ? 32 : 0), lane,
-                        p == 0 ? seg_dst : nullptr, (uint32_t)(relbits + excl));
-  }
-}
-
-template <typename E>
-__device__ __forceinline__ void lookup16(const typename E::T* tab, const uint4& v, int lane, typename E::T (&e)[16]) {
-  const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const uint32_t b = (vv[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-#if defined(GHF_EXP) && GHF_EXP == 7
-    e[j] = (typename E::T)((b << 8) | 8u);
-#else
-    e[j] = tab[E::slot(b, (uint32_t)lane)];
-#endif
-  }
-}
-
-template <typename M>
-__device__ __forceinline__ void emit_chunk(const EmitParams& P, uint32_t c, const typename M::E::T* tab, uint32_t* st,
-                                           uint64_t start_bit, uint64_t origin_byte, int lane) {
-  typedef typename M::E E;
-  typedef typename E::T ET;
-  const uint64_t chunk = 1ull << P.chunk_log2;
-  const uint64_t sym0 = (uint64_t)c << P.chunk_log2;
-  const uint64_t nsym = (P.n - sym0 < chunk) ? (P.n - sym0) : chunk;
-  const uint8_t* pin = P.in + sym0;
-  const bool aligned = (((uintptr_t)pin) & 15u) == 0;
-  const uint64_t Pc = start_bit + P.chunk_off[c];
-  WaveOut W;
-  W.st = st;
-  W.out_units = reinterpret_cast<uint4*>(P.out);
-  W.unit_base = (Pc >> 7) - (origin_byte >> 4);
-  W.carry = (uint32_t)(Pc & 127u);
-  W.cw = 0;
-  W.first_pending = true;
-  if (lane < 8) st[lane] = 0;
-  if (lane == 0 && P.chunk_bit) P.chunk_bit[c] = Pc - origin_byte * 8;  // relative to d_out[0]
-  wave_sync();
-  uint64_t relbits = 0;
-  const uint64_t nfull = aligned ? (nsym / kSymPerIter) : 0;
-  const uint4* pv = reinterpret_cast<const uint4*>(pin) + lane;
-  uint32_t* const segp = P.seg_bit ? P.seg_bit + ((sym0 + (uint64_t)lane * 16) >> 6) : nullptr;
-  uint64_t it = 0;
-  // ---- full 1 KiB tiles, two per trip.  While tile `it` is packed, the loads of tiles it+1 and it+2 are in flight;
-  //      A and B are each re-loaded right after they were consumed, so no register ever has to be copied while
-  //      its load is pending (the last prefetches are clamped to the last full tile and simply unused).
-  if (nfull >= 2) {
-    uint4 A = pv[0], B = pv[64];
-    __builtin_amdgcn_s_waitcnt(0x0F71);  // vmcnt(1): A has arrived, so the loop is entered in the state its back edge leaves
-    for (; it + 1 < nfull; it += 2) {
-      {
-        const uint4 v = A;
-        const uint64_t nx = (it + 2 < nfull) ? it + 2 : nfull - 1;
-        A = pv[nx * 64];
-        ET e[16];
-        lookup16<E>(tab, v, lane, e);
-        Items<M::N> items;
-        make_items<M>(e, items);
-        uint32_t total;
-        emit_iteration<M::N, true>(W, items, lane, segp ? segp + it * 16 : nullptr, relbits, true, total);
-        relbits += total;
-      }
-      {
-        const uint4 v = B;
-        const uint64_t nx = (it + 3 < nfull) ? it + 3 : nfull - 1;
-        B = pv[nx * 64];
-        ET e[16];
-        lookup16<E>(tab, v, lane, e);
-        Items<M::N> items;
-        make_items<M>(e, items);
-        uint32_t total;
-        emit_iteration<M::N, true>(W, items, lane, segp ? segp + (it + 1) * 16 : nullptr, relbits, true, total);
-        relbits += total;
-      }
-    }
-  }
-  // ---- whatever is left: an odd full tile, the ragged tail, unaligned input, and -- on the stream's last chunk --
-  //      one extra pass for the end mark and the padding (canonical_huff_encoder.cc:255-257, buffer.h:277-280)
-  const uint64_t niter = (nsym + kSymPerIter - 1) / kSymPerIter;
-  const bool last = (P.flags & GHF_EMIT_LAST) && c + 1 == P.nchunks;
-  const uint64_t nsteps = niter + (last ? 1 : 0);
-  for (; it < nsteps; ++it) {
-    Items<M::N> items;
-    bool seg_valid = false;
-    uint32_t* seg_out = nullptr;
-    if (it < niter) {
-      const uint64_t sb = it * kSymPerIter;
-      const uint64_t rem = nsym - sb;
-      uint4 v;
-      uint32_t cnt = 16;
-      if (aligned && rem >= (uint64_t)kSymPerIter) {
-        v = pv[it * 64];
-      } else {  // byte loads, never past the end of the buffer
-        const uint64_t lo = (uint64_t)lane * 16;
-        cnt = rem > lo ? (rem - lo >= 16 ? 16u : (uint32_t)(rem - lo)) : 0u;
-        uint32_t q[4] = {0, 0, 0, 0};
-        for (uint32_t j = 0; j < cnt; ++j) q[j >> 2] |= (uint32_t)pin[sb + lo + j] << (8 * (j & 3));
-        v = make_uint4(q[0], q[1], q[2], q[3]);
-      }
-      ET e[16];
-      lookup16<E>(tab, v, lane, e);
-      if (cnt < 16) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if ((uint32_t)j >= cnt) e[j] = 0;
-      }
-      make_items<M>(e, items);
-      seg_valid = cnt != 0;
-      seg_out = segp ? segp + it * 16 : nullptr;
-    } else {
-      const uint32_t el = P.code->length[GHF_NSYM - 1], ec = P.code->codeword[GHF_NSYM - 1];
-      const uint32_t pad = (uint32_t)((0 - (Pc + relbits + el)) & 7u);
-#pragma unroll
-      for (int j = 0; j < M::N; ++j) {
-        items.code[j] = 0;
-        items.len[j] = 0;
-      }
-      if (lane == 0) {
-        items.code[0] = ec;
-        items.len[0] = el;
-        items.code[1] = (1u << pad) - 1u;
-        items.len[1] = pad;
-      }
-    }
-    uint32_t total;
-    emit_iteration<M::N, false>(W, items, lane, seg_out, relbits, seg_valid, total);
-    relbits += total;
-  }
-  // the chunk's last, incomplete unit is shared with the next chunk (or is the end of the stream)
-  if (W.carry) or_unit_words(W.out_units + W.unit_base, st, lane);
-}
-
-template <typename M>
-__global__ __launch_bounds__(kEmitThreads, M::kMinWaves) void k_emit(EmitParams P) {
-  typedef typename M::E E;
-  __shared__ __attribute__((aligned(16))) typename E::T tab[256 * E::kRep];  // 32 KiB: [256][32] u32 or [256][16] u64
-  __shared__ __attribute__((aligned(16))) uint32_t stage[kEmitWaves][kStageWords];
-  __shared__ int status0;
-  const int tid = threadIdx.x;
-  if (tid == 0) status0 = *P.status;  // a previous stage failed -> uniform exit
-  __syncthreads();
-  if (status0 != 0) return;
-  const int max_len = P.code->max_len;
-  if (!M::applies(max_len)) return;
-  for (int i = tid; i < 256 * (int)E::kRep; i += kEmitThreads) {
-    const int s = i / (int)E::kRep;
-    tab[i] = E::make(P.code->codeword[s], P.code->length[s]);
-  }
-  __syncthreads();
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell the compiler it is wave-uniform (SGPR)
-  const uint64_t start_bit = P.d_start_bit ? *P.d_start_bit : 8ull * (1040ull + 8ull * (uint64_t)max_len);
-  const uint64_t origin_byte = (P.flags & GHF_EMIT_REBASE) ? ((start_bit >> 7) << 4) : 0ull;
-  // one chunk per wave when the grid covers all chunks (PairMode); WideMode is launched with a small grid (it usually
-  // has nothing to do, and an early exit of 1024 workgroups still costs ~5 us of dispatch) and strides over the chunks
-  if constexpr (M::kStrided) {
-    for (uint32_t c = blockIdx.x * kEmitWaves + wave; c < P.nchunks; c += gridDim.x * kEmitWaves)
-      emit_chunk<M>(P, c, tab, stage[wave], start_bit, origin_byte, lane);
-  } else {
-    const uint32_t c = blockIdx.x * kEmitWaves + wave;
-    if (c < P.nchunks) emit_chunk<M>(P, c, tab, stage[wave], start_bit, origin_byte, lane);
-  }
-}
-
-// zero the 16-byte units two chunks share, check the capacity, report where the stream ends
-__global__ __launch_bounds__(256) void k_emit_prep(EmitParams P) {
-  if (*P.status != 0) return;
-  const int max_len = P.code->max_len;
-  const uint64_t start_bit = P.d_start_bit ? *P.d_start_bit : 8ull * (1040ull + 8ull * (uint64_t)max_len);
-  const uint64_t origin_byte = (P.flags & GHF_EMIT_REBASE) ? ((start_bit >> 7) << 4) : 0ull;
-  const uint64_t body_end = start_bit + P.chunk_off[P.nchunks];
-  uint64_t end = body_end;
-  if (P.flags & GHF_EMIT_LAST) {
-    end += P.code->length[GHF_NSYM - 1];
-    end = (end + 7) & ~7ull;
-  }
-  const uint64_t end_byte = ((end + 7) >> 3) - origin_byte;
-  const uint64_t end_unit_bytes = (((end >> 7) + 1) << 4) - origin_byte;  // through the unit holding the end bit
-  const bool fits = end_unit_bytes <= P.cap || (((end & 127u) == 0) && end_byte <= P.cap);
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) {
-    if (!fits) latch_status(P.status, GHF_E_CAP);
-    if (P.d_end) {
-      P.d_end[0] = end;
-      P.d_end[1] = end_byte;
-    }
-  }
-  if (!fits) return;
-  if (i < P.nchunks) {
-    const uint64_t Pc = start_bit + P.chunk_off[i];
-    uint8_t* u = P.out + (((Pc >> 7) << 4) - origin_byte);
-    if (i == 0 && !(P.flags & GHF_EMIT_REBASE)) {
-      // bytes in front of the first code (the header) stay
-      const uint64_t ub = (Pc >> 7) << 7;
-      for (int b = 0; b < 16; ++b) {
-        const uint64_t bit0 = ub + 8ull * b;
-        if (bit0 >= Pc) u[b] = 0;
-        else if (bit0 + 8 > Pc) u[b] &= (uint8_t)(0xFFu << (8 - (uint32_t)(Pc - bit0)));
-      }
-    } else {
-      *reinterpret_cast<uint4*>(u) = make_uint4(0, 0, 0, 0);
-    }
-  } else if (i == P.nchunks) {
-    if ((end & 127u) != 0 && (end >> 7) != (start_bit >> 7)) {
-      uint8_t* u = P.out + (((end >> 7) << 4) - origin_byte);
-      *reinterpret_cast<uint4*>(u) = make_uint4(0, 0, 0, 0);
-    }
-  } else if ((P.flags & GHF_EMIT_HEADER) && !(P.flags & GHF_EMIT_REBASE)) {
-    // a5, canonical_huff_encoder.cc:210-242: the header words in front of the body.  The first code sits right
-    // behind the header (start_bit is its end), and chunk 0's thread above only clears bytes from start_bit on.
-    const int w = (int)(i - P.nchunks - 1);
-    const int nwords = 1 + GHF_NSYM + 2 + 2 * max_len;
-    if (w < nwords && (uint64_t)(w + 1) * 32 <= start_bit) reinterpret_cast<uint32_t*>(P.out)[w] = bswap32(header_word(P.code, w, max_len));
-  }
-}
-
-void launch_emit(const EmitParams& p, hipStream_t s) {
-  const uint32_t prep_blocks = (p.nchunks + 1 + ((p.flags & GHF_EMIT_HEADER) ? 1 + GHF_NSYM + 2 + 64 : 0) + 255) / 256;
-  hipLaunchKernelGGL(k_emit_prep, dim3(prep_blocks), dim3(256), 0, s, p);
-  const uint32_t blocks = (p.nchunks + kEmitWaves - 1) / kEmitWaves;
-  hipLaunchKernelGGL(k_emit<PairMode>, dim3(blocks), dim3(kEmitThreads), 0, s, p);
-  hipLaunchKernelGGL(k_emit<WideMode>, dim3(blocks < 512u ? blocks : 512u), dim3(kEmitThreads), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ INDEX_NO_END_MARK = 1
 CODE_LIMIT = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("GHF_LIB") or os.path.join(_HERE, "lib", "libghf.so")  # GHF_LIB: experiment builds only
+LIB_PATH = os.path.join(_HERE, "lib", "libghf.so")
 
 STATUS = {0: "ok", 1: "invalid argument", 2: "HIP error / no device", 3: "empty input", 4: "code longer than 32 bits",
           5: "output capacity too small", 6: "not a .crs2 / .crs header", 7: "corrupt stream", 8: "out of memory",

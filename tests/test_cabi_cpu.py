@@ -123,11 +123,8 @@ def test_crs_parse_header_rejects_garbage(ghf, golden_crs):
     assert e.value.status == 4
 
 
-def test_emit_kernels_have_no_scratch():
-    """K5's main loop times its memory operations with explicit s_waitcnt vmcnt(1) (one per tile); that reasoning assumes
-    the only vector-memory operations in flight are its own tile loads and stores.  Register spills would add scratch
-    traffic to the same counter -- a build of the Pair variant that spilled six registers produced wrong streams -- so
-    the build must keep both variants spill-free (checked on the compiler's own resource report)."""
+def _kernel_asm(name):
+    """gfx950 ISA text of golden-huffman_amd/csrc/<name>.hip, built with the Makefile's own flags"""
     import shutil
     import subprocess
     import tempfile
@@ -135,7 +132,7 @@ def test_emit_kernels_have_no_scratch():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc here")
-    src = os.path.join(ROOT, "golden-huffman_amd", "csrc", "ghf_kernels.hip")
+    src = os.path.join(ROOT, "golden-huffman_amd", "csrc", name + ".hip")
     mk = open(os.path.join(ROOT, "golden-huffman_amd", "Makefile")).read()
     flags = re.search(r"^HIPFLAGS \?= (.*)$", mk, flags=re.M).group(1)
     flags = flags.replace("$(ARCH)", "gfx950").replace("$(ROOT)", ROOT).replace("$(HERE)", os.path.join(ROOT, "golden-huffman_amd") + "/")
@@ -143,15 +140,27 @@ def test_emit_kernels_have_no_scratch():
         r = subprocess.run([hipcc] + flags.split() + ["--cuda-device-only", "-S", "-o", os.path.join(td, "k.s"), src],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        text = open(os.path.join(td, "k.s")).read()
+        return open(os.path.join(td, "k.s")).read()
+
+
+def test_emit_kernel_has_no_scratch():
+    """K5's main loop times its memory operations with an explicit s_waitcnt vmcnt(1) per tile; that reasoning assumes
+    the only vector-memory operations in flight are its own tile loads and stores.  Register spills would add scratch
+    traffic to the same counter, so the build must keep the kernel spill-free (checked on the
+    compiler's own resource report)."""
+    text = _kernel_asm("ghf_emit")
     seen = 0
-    for m in re.finditer(r"\.name:\s+(\S*k_emitI\S*)(.*?)\.wavefront_size", text, flags=re.S):
+    for m in re.finditer(r"\.name:\s+(\S*k_emit\S*)(.*?)\.wavefront_size", text, flags=re.S):
         body = m.group(2)
         spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", body).group(1))
         priv = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
         assert spill == 0 and priv == 0, (m.group(1), spill, priv)
         seen += 1
-    assert seen == 2
+    assert seen == 1
+
+
+def test_decode_kernel_scratch_reloads_are_followed_by_full_waits():
+    text = _kernel_asm("ghf_kernels")
     # K7 may spill (its 128-VGPR budget is tight), but only where it does no harm: every scratch reload must be
     # followed by a FULL vector-memory wait before any counted one (so nothing is ever inferred from the order in
     # which a scratch reload and a global load retire)
