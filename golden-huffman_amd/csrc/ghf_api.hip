@@ -332,7 +332,7 @@ int ghf_encode_emit(ghf_ctx* c, const uint8_t* d_in, size_t n, const ghf_code* d
   const uint32_t cl = chunk_log2_for(n);
   const size_t nchunks = (n + ((size_t)1 << cl) - 1) >> cl;
   if (index) {
-    if (index->n_symbols != n || index->chunk_symbols != (1u << cl) || index->seg_symbols != (uint32_t)kSegSymbols ||
+    if (index->n_symbols != n || index->chunk_symbols != (uint32_t)kBlockSymbols || index->seg_symbols != (uint32_t)kSegSymbols ||
         !index->d_chunk_bit || !index->d_seg_bit)
       return fail(c, GHF_E_INVAL, "ghf_encode_emit: index does not match n (use ghf_index_alloc)");
   }
@@ -394,11 +394,10 @@ int ghf_index_alloc(ghf_ctx* c, size_t n_symbols, ghf_index* out) {
   if (!c || !out) return GHF_E_INVAL;
   GHF_HIP(c, hipSetDevice(c->device));
   std::memset(out, 0, sizeof *out);
-  const uint32_t cl = chunk_log2_for(n_symbols);
   out->n_symbols = n_symbols;
-  out->chunk_symbols = 1u << cl;
+  out->chunk_symbols = kBlockSymbols;
   out->seg_symbols = kSegSymbols;
-  out->n_chunks = (n_symbols + ((size_t)1 << cl) - 1) >> cl;
+  out->n_chunks = (n_symbols + kBlockSymbols - 1) / kBlockSymbols;
   out->n_segs = (n_symbols + kSegSymbols - 1) / kSegSymbols;
   GHF_HIP(c, hipMalloc(&out->d_chunk_bit, std::max<size_t>(out->n_chunks, 1) * sizeof(uint64_t)));
   hipError_t e = hipMalloc(&out->d_seg_bit, std::max<size_t>(out->n_segs, 1) * sizeof(uint32_t));
@@ -587,8 +586,7 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
   if (n > cap) return fail(c, GHF_E_CAP, "ghf_decode: output capacity below the decoded size");
   // size the side-car
   ghf_index& ix = c->fidx;
-  const uint32_t cl = chunk_log2_for(n);
-  const uint64_t n_chunks = (n + ((uint64_t)1 << cl) - 1) >> cl, n_segs = (n + kSegSymbols - 1) / kSegSymbols;
+  const uint64_t n_chunks = (n + kBlockSymbols - 1) / kBlockSymbols, n_segs = (n + kSegSymbols - 1) / kSegSymbols;
   if (n_segs > c->fidx_cap_segs) {
     if (ix.d_seg_bit) (void)hipFree(ix.d_seg_bit);
     if (c->d_seg_abs) (void)hipFree(c->d_seg_abs);
@@ -596,7 +594,7 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
     c->d_seg_abs = nullptr;
     c->fidx_cap_segs = 0;
     GHF_HIP(c, hipMalloc(&ix.d_seg_bit, n_segs * sizeof(uint32_t)));
-    GHF_HIP(c, hipMalloc(&c->d_seg_abs, n_segs * sizeof(uint64_t)));
+    GHF_HIP(c, hipMalloc(&c->d_seg_abs, (n_segs + 1) * sizeof(uint64_t)));
     c->fidx_cap_segs = n_segs;
   }
   if (n_chunks > c->fidx_cap_chunks) {
@@ -607,12 +605,12 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
     c->fidx_cap_chunks = n_chunks;
   }
   ix.n_symbols = n;
-  ix.chunk_symbols = 1u << cl;
+  ix.chunk_symbols = kBlockSymbols;
   ix.seg_symbols = kSegSymbols;
   ix.n_chunks = n_chunks;
   ix.n_segs = n_segs;
   ix.flags = (mode == 2 && eof_sub >= p.nsub) ? (uint32_t)GHF_INDEX_NO_END_MARK : 0u;
-  if (n) launch_sync_index(p, c->d_seg_abs, n_segs, cl, ix.d_chunk_bit, ix.d_seg_bit, c->stream);
+  if (n) launch_sync_index(p, c->d_seg_abs, n, ix.d_chunk_bit, ix.d_seg_bit, c->stream);
   GHF_HIP(c, hipGetLastError());
   c->fidx_stream = d_stream;
   c->fidx_bytes = stream_bytes;
@@ -688,7 +686,7 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
     index = &c->fidx;
   }
   if (!index->d_chunk_bit || !index->d_seg_bit || index->seg_symbols != (uint32_t)kSegSymbols ||
-      (index->chunk_symbols & (index->chunk_symbols - 1)) || index->chunk_symbols < (uint32_t)kSegSymbols)
+      index->chunk_symbols != (uint32_t)kBlockSymbols || index->n_segs != (index->n_symbols + kSegSymbols - 1) / kSegSymbols)
     return fail(c, GHF_E_INVAL, "ghf_decode: malformed index");
   if (cap < index->n_symbols) return fail(c, GHF_E_CAP, "ghf_decode: output capacity below n_symbols");
   DecParams p;
@@ -699,9 +697,6 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
   p.seg_bit = index->d_seg_bit;
   p.n_symbols = index->n_symbols;
   p.n_segs = index->n_segs;
-  uint32_t cl = 0;
-  while ((1u << cl) < index->chunk_symbols) ++cl;
-  p.chunk_log2 = cl;
   p.no_end_mark = (index->flags & GHF_INDEX_NO_END_MARK) ? 1u : 0u;
   p.out = d_out;
   p.status = c->d_status;
@@ -860,7 +855,7 @@ int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int
     index = &c->fidx;
   }
   if (!index->d_chunk_bit || !index->d_seg_bit || index->seg_symbols != (uint32_t)kSegSymbols ||
-      (index->chunk_symbols & (index->chunk_symbols - 1)) || index->chunk_symbols < (uint32_t)kSegSymbols)
+      index->chunk_symbols != (uint32_t)kBlockSymbols || index->n_segs != (index->n_symbols + kSegSymbols - 1) / kSegSymbols)
     return fail(c, GHF_E_INVAL, "ghf_crs_decode: malformed index");
   if (cap < index->n_symbols) return fail(c, GHF_E_CAP, "ghf_crs_decode: output capacity below n_symbols");
   DecParams p;
@@ -871,9 +866,6 @@ int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int
   p.seg_bit = index->d_seg_bit;
   p.n_symbols = index->n_symbols;
   p.n_segs = index->n_segs;
-  uint32_t cl = 0;
-  while ((1u << cl) < index->chunk_symbols) ++cl;
-  p.chunk_log2 = cl;
   p.no_end_mark = 1u;  // there is none in this format; the end of every segment but the last is checked against the side-car
   p.out = d_out;
   p.status = c->d_status;

@@ -1,0 +1,934 @@
+// golden-huffman_amd/csrc/ghf_decode.hip -- K7 (table-driven block-parallel decode) and K6 (side-car reconstruction
+// for streams that come without one), gfx950 / wave64.  File:line citations are relative to the reference tree.
+#include "ghf_device.h"
+
+namespace ghf {
+
+// ------------------------------------------------------------------------------------------------
+// K7: decode.  k_build_decode_tables turns the header tables into left-justified first codes
+// (FastCanonicalHuffDecoder, canonical_huff_encoder.cc:433-434) and a 2^lut_bits direct table
+// {symbol, length} -- the reference's 8-bit length LUT (canonical_huff_encoder.cc:466-516) widened
+// to min(max_len, 12) bits so that no linear extension is needed at any BASELINE config; longer
+// codes fall back to the reference's linear search over first_code (cfind, canonical_huff_encoder.h:157-162).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_decode_tables(const ghf_code* __restrict__ code, DecTables* __restrict__ dt,
+                                                             int* __restrict__ status) {
+  __shared__ uint32_t fcl[36];
+  __shared__ uint32_t sp[36];
+  const int tid = threadIdx.x;
+  const int max_len = code->max_len, min_len = code->min_len;
+  if (max_len < 1 || max_len > 32 || min_len < 1 || min_len > max_len) {
+    if (tid == 0) latch_status(status, GHF_E_FORMAT);
+    return;
+  }
+  const int lb = max_len < kDecLutBitsMax ? max_len : kDecLutBitsMax;
+  if (tid < 36) {
+    uint32_t f = 0xFFFFFFFFu, p = 0;
+    if (tid >= min_len && tid <= max_len) {
+      f = code->first_code[tid] << (32 - tid);
+      p = code->start_pos[tid];
+    }
+    fcl[tid] = f;
+    sp[tid] = p;
+    dt->fc_left[tid] = f;
+    dt->start_pos[tid] = p;
+  }
+  for (int i = tid; i < GHF_NSYM; i += 256) dt->symbol[i] = (uint16_t)(code->symbol[i] > 256u ? 256u : code->symbol[i]);
+  if (tid == 0) {
+    dt->min_len = min_len;
+    dt->max_len = max_len;
+    dt->lut_bits = lb;
+    dt->kind = 0;
+    dt->root = 0;
+  }
+  if (tid < 16) dt->ticket[tid * 32] = 0;
+  __syncthreads();
+  for (uint32_t idx = tid; idx < (1u << lb); idx += 256) {
+    const uint32_t v = idx << (32 - lb);
+    uint16_t ent = 0;
+    for (int len = min_len; len <= lb; ++len) {
+      if (v >= fcl[len]) {
+        const uint32_t k = sp[len] + ((v - fcl[len]) >> (32 - len));
+        const uint32_t sym = k < GHF_NSYM ? code->symbol[k] : 256u;
+        ent = (uint16_t)((sym > 256u ? 256u : sym) | ((uint32_t)len << 9));
+        break;
+      }
+    }
+    dt->lut[idx] = ent;
+  }
+  // two symbols per lookup when any two codes fit the index (small alphabets: 16-symbol data has max_len 5)
+  const int pb = 2 * max_len <= kDecPairBitsMax ? 2 * max_len : 0;
+  if (tid == 0) dt->pair_bits = pb;
+  auto one = [&](uint32_t v) -> uint32_t {  // sym | len << 9 of the code at the top of v; 0: none
+    for (int len = min_len; len <= max_len; ++len) {
+      if (v >= fcl[len]) {
+        const uint32_t k = sp[len] + ((v - fcl[len]) >> (32 - len));
+        const uint32_t sym = k < GHF_NSYM ? code->symbol[k] : 256u;
+        return (sym > 256u ? 256u : sym) | ((uint32_t)len << 9);
+      }
+    }
+    return 0u;
+  };
+  for (uint32_t idx = tid; pb && idx < (1u << pb); idx += 256) {
+    const uint32_t v = idx << (32 - pb);
+    const uint32_t e0 = one(v);
+    uint32_t ent = (1u << 30) | (1u << 16);  // not a data symbol: flagged, one bit consumed
+    if (e0 && (e0 & 0x1FFu) != 256u) {
+      const uint32_t l0 = e0 >> 9;
+      const uint32_t e1 = one(v << l0);
+      if (e1 && (e1 & 0x1FFu) != 256u) ent = (e0 & 0xFFu) | ((e1 & 0xFFu) << 8) | ((l0 + (e1 >> 9)) << 16);
+      else ent = (1u << 30) | (l0 << 16);
+    }
+    dt->lut2[idx] = ent;
+  }
+}
+
+// .crs: the same direct table, filled by walking the tree DecodeHuffTree::do_build_tree would rebuild
+// (include/huff_tree.cc:289-303); what the table cannot resolve is walked bit by bit like decode_byte does (:255-271).
+__global__ __launch_bounds__(256) void k_crs_decode_tables(const ghf_tree* __restrict__ tree, DecTables* __restrict__ dt,
+                                                           int* __restrict__ status) {
+  __shared__ uint16_t tl[256], tr[256];
+  __shared__ uint32_t s_min;
+  const int tid = threadIdx.x;
+  const int max_len = (int)tree->max_len;
+  const uint32_t root = tree->root, nl = tree->n_leaves;
+  if (max_len < 1 || max_len > 32 || nl < 2 || nl > 256 || root < 256 || root >= 256 + nl - 1) {
+    if (tid == 0) latch_status(status, GHF_E_FORMAT);
+    return;
+  }
+  tl[tid] = tree->left[tid];
+  tr[tid] = tree->right[tid];
+  if (tid == 0) s_min = 64;
+  __syncthreads();
+  const int lb = max_len < kDecLutBitsMax ? max_len : kDecLutBitsMax;
+  dt->tl[tid] = tl[tid];
+  dt->tr[tid] = tr[tid];
+  if (tid < 36) {
+    dt->fc_left[tid] = 0xFFFFFFFFu;
+    dt->start_pos[tid] = 0;
+  }
+  for (int i = tid; i < GHF_NSYM; i += 256) dt->symbol[i] = 256;
+  if (tid < 16) dt->ticket[tid * 32] = 0;
+  uint32_t mn = 64;
+  for (uint32_t idx = tid; idx < (1u << lb); idx += 256) {
+    uint32_t node = root;
+    uint16_t ent = 0;
+    for (int l = 1; l <= lb; ++l) {
+      const uint32_t p = node - 256u;
+      if (p >= nl - 1) break;  // a child id that is neither a leaf nor one of the nl - 1 parents: malformed, entry stays 0
+      node = ((idx >> (lb - l)) & 1u) ? tr[p] : tl[p];
+      if (node < 256u) {
+        ent = (uint16_t)(node | ((uint32_t)l << 9));
+        mn = (uint32_t)l < mn ? (uint32_t)l : mn;
+        break;
+      }
+    }
+    dt->lut[idx] = ent;
+  }
+  atomicMin(&s_min, mn);
+  __syncthreads();
+  if (tid == 0) {
+    dt->min_len = (int32_t)(s_min <= (uint32_t)lb ? s_min : (uint32_t)lb);
+    dt->max_len = max_len;
+    dt->lut_bits = lb;
+    dt->pair_bits = 0;
+    dt->kind = 1;
+    dt->root = root;
+  }
+}
+
+void launch_crs_decode_tables(const ghf_tree* d_tree, DecTables* d_dt, int* d_status, hipStream_t s) {
+  hipLaunchKernelGGL(k_crs_decode_tables, dim3(1), dim3(256), 0, s, d_tree, d_dt, d_status);
+}
+
+void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_status, hipStream_t s) {
+  hipLaunchKernelGGL(k_build_decode_tables, dim3(1), dim3(256), 0, s, d_code, d_dt, d_status);
+}
+
+struct DecLds {  // K6 (side-car reconstruction): 4 waves, plain table
+  alignas(16) uint32_t in[kDecWaves][kDecInWords + 4];
+  alignas(16) uint16_t lut[1 << kDecLutBitsMax];
+  uint32_t fcl[36];
+  uint32_t sp[36];
+  uint16_t symbol[GHF_NSYM + 3];
+  uint16_t tl[256], tr[256];  // kind 1 (.crs): the tree
+  uint32_t root;
+  int kind;
+  int status0;
+};
+
+// K7 keeps the direct table in LDS as 32-bit entries, REPLICATED so that the 64 random lookups of a wave do not pile
+// up on a few banks: the table gets 64 KiB = 16384 slots; with lut_bits index bits there is room for
+// R = min(32, 2^(14 - lut_bits)) copies, slot = index * R + lane % R.  Up to 9-bit tables (uniform bytes: 8/9-bit codes)
+// that is one bank per lane of a 32-lane LDS group: conflict-free whatever the data (PMC, 256 MiB uniform, round 1:
+// 74 % of the LDS cycles of the 16-bit / 16-copy layout were bank-conflict cycles).  12-bit tables get 4 copies (skewed
+// data hits few, mostly identical entries anyway: identical addresses broadcast).
+//   entry = symbol | length << 8 | bit 16: end mark | bit 17: no code of <= lut_bits bits starts with these bits
+// The room comes from the output: a lane keeps its 64 decoded bytes in 16 registers and the wave's INPUT tile, dead by
+// then, serves as the transposition buffer for the coalesced copy-out.
+constexpr int kDec7Threads = 1024;
+constexpr int kDec7Waves = kDec7Threads / kWave;
+constexpr int kDec7LutLog2 = 14;
+constexpr int kDec7LutSlots = 1 << kDec7LutLog2;
+constexpr int kDec7SmallSlots = 1024;  // pair mode (max_len <= 5): the one-symbol table for ragged tails and the end mark, 32 copies
+constexpr int kDec7InBytes = 4608;  // staged span per wave: 4096 symbols at <= 9 bits average (a byte-Huffman code averages <= 8.1)
+constexpr int kDec7InWords = kDec7InBytes / 4;
+constexpr uint32_t kEntEnd = 1u << 16, kEntNone = 1u << 17;
+struct DecLds7 {
+  alignas(16) uint32_t in[kDec7Waves][kDec7InWords + 4];  // compressed span of the wave's group, big-endian words; then its output
+  alignas(16) uint32_t lut[kDec7LutSlots + kDec7SmallSlots];
+  uint32_t fcl[36];
+  uint32_t sp[36];
+  uint16_t symbol[GHF_NSYM + 3];
+  uint16_t tl[256], tr[256];  // kind 1 (.crs): the tree
+  uint32_t root;
+  int kind;
+  int status0;
+};
+static_assert(sizeof(DecLds7) <= 160 * 1024, "one workgroup of 16 waves per CU");
+template <typename LT>
+__device__ __forceinline__ void dec_small_load(LT& L, const DecTables* dt, int tid, int nthreads) {
+  if (tid < 36) {
+    L.fcl[tid] = dt->fc_left[tid];
+    L.sp[tid] = dt->start_pos[tid];
+  }
+  for (int i = tid; i < GHF_NSYM; i += nthreads) L.symbol[i] = dt->symbol[i];
+  for (int i = tid; i < 256; i += nthreads) {
+    L.tl[i] = dt->tl[i];
+    L.tr[i] = dt->tr[i];
+  }
+  if (tid == 0) {
+    L.kind = dt->kind;
+    L.root = dt->root;
+  }
+}
+
+__device__ __forceinline__ void dec_lds_load(DecLds& L, const DecTables* dt, int tid, int nthreads) {
+  const int lut_bits = dt->lut_bits;
+  const uint4* src = reinterpret_cast<const uint4*>(dt->lut);
+  uint4* dst = reinterpret_cast<uint4*>(L.lut);
+  for (int i = tid; i < ((1 << lut_bits) * 2 + 15) / 16; i += nthreads) dst[i] = src[i];
+  dec_small_load(L, dt, tid, nthreads);
+}
+
+__device__ __forceinline__ uint32_t dec7_entry(uint32_t g) {  // DecTables::lut entry (sym | len << 9) -> LDS entry
+  const uint32_t sym = g & 0x1FFu, len = g >> 9;
+  return (sym & 0xFFu) | (len << 8) | (sym == 256u ? kEntEnd : 0u) | (len == 0u ? kEntNone : 0u);
+}
+
+// replicated fill: one-symbol table, entry idx, copy r at lut[(idx << rlog) | r]; with a pair table (small alphabets)
+// the 64 KiB hold lut2 (two symbols per entry) and the one-symbol table goes into the small region behind it
+__device__ __forceinline__ void dec_lds_load7(DecLds7& L, const DecTables* dt, int tid, int nthreads) {
+  const int pb = dt->pair_bits, lb = dt->lut_bits;
+  if (pb) {
+    const int r2 = (kDec7LutLog2 - pb) < 5 ? (kDec7LutLog2 - pb) : 5;
+    for (int i = tid; i < (1 << (pb + r2)); i += nthreads) L.lut[i] = dt->lut2[i >> r2];
+    for (int i = tid; i < kDec7SmallSlots; i += nthreads) L.lut[kDec7LutSlots + i] = dec7_entry(dt->lut[(i >> 5) & ((1 << lb) - 1)]);
+  } else {
+    const int r1 = (kDec7LutLog2 - lb) < 5 ? (kDec7LutLog2 - lb) : 5;
+    for (int i = tid; i < (1 << (lb + r1)); i += nthreads) L.lut[i] = dec7_entry(dt->lut[i >> r1]);
+  }
+  dec_small_load(L, dt, tid, nthreads);
+}
+
+// codes longer than the direct table: the reference's linear extension (canonical_huff_encoder.cc:554-557).
+// returns sym | len << 16
+template <typename LT>
+__device__ __forceinline__ uint32_t dec_long(const LT& L, uint32_t hi, int lut_bits, int max_len) {
+  if (L.kind == 1) {  // .crs: walk the tree from the root (huff_tree.cc:255-271); malformed trees end in "no symbol"
+    uint32_t node = L.root;
+    for (int l = 1; l <= max_len; ++l) {
+      const uint32_t p = node - 256u;
+      if (p >= 256u) break;
+      node = ((hi >> (32 - l)) & 1u) ? L.tr[p] : L.tl[p];
+      if (node < 256u) return node | ((uint32_t)l << 16);
+    }
+    return 256u | ((uint32_t)max_len << 16);
+  }
+  int l = lut_bits + 1;
+  if (l > max_len) return 256u | ((uint32_t)max_len << 16);  // an incomplete table (bits no code starts with): no symbol
+  while (l < max_len && hi < L.fcl[l]) ++l;
+  const uint32_t k = L.sp[l] + ((hi - L.fcl[l]) >> (32 - l));
+  return (k < GHF_NSYM ? (uint32_t)L.symbol[k] : 256u) | ((uint32_t)l << 16);
+}
+
+template <bool STAGED>
+struct DecIn {
+  const uint32_t* in;   // staged big-endian words
+  const uint8_t* src;   // unstaged: raw bytes of the span
+  uint64_t span;
+  __device__ __forceinline__ uint32_t fetch(uint32_t widx) const {
+    if (STAGED) return in[widx];
+    const uint64_t b = (uint64_t)widx * 4;
+    uint32_t r = 0;
+    for (int k = 0; k < 4; ++k) r = (r << 8) | (b + k < span ? (uint32_t)src[b + k] : 0u);
+    return r;
+  }
+};
+
+// what a lane needs to look codes up in ITS replica of a table
+struct DecLut {
+  const char* base;  // table + 4 * (lane % copies)
+  int lsh;           // 32 - index bits
+  int ash;           // log2(copies) + 2
+};
+__device__ __forceinline__ uint32_t dec_lookup(const DecLut& T, uint32_t v) {
+  return *reinterpret_cast<const uint32_t*>(T.base + ((v >> T.lsh) << T.ash));
+}
+template <typename LT>
+__device__ __forceinline__ uint32_t dec_long_entry(const LT& L, uint32_t v, int lut_bits, int max_len) {
+  const uint32_t r = dec_long(L, v, lut_bits, max_len);  // sym | len << 16
+  return (r & 0xFFu) | ((r >> 16) << 8) | ((r & 0x100u) << 8);
+}
+
+// The window W holds 64 stream bits, `o` of them (from the top) already consumed; one symbol costs a 64-bit shift, the
+// table lookup and an add.  K symbols are decoded between two refill checks -- K * max_len <= 33 keeps o + max_len <= 64
+// at every lookup.
+#define GHF_REFILL()       \
+  if (o >= 32u) {          \
+    W = (W << 32) | nextw; \
+    o -= 32u;              \
+    nextw = *wp++;         \
+  }
+
+// HOT: the 64 symbols of a full, staged segment whose codes all fit the direct table.  Straight-line code; the 64 bytes
+// stay in registers.  Returns the OR of all entries (kEntEnd / kEntNone set: not 64 data symbols -> corrupt).
+template <int K>
+__device__ __forceinline__ uint32_t dec_hot(const uint32_t* in, const DecLut& T, uint32_t pos, uint32_t (&out)[16], uint32_t& used) {
+  const uint32_t* wp = in + (pos >> 5);
+  const uint32_t* const wp0 = wp;
+  uint32_t o = pos & 31u;
+  const uint32_t o0 = o;
+  uint64_t W = ((uint64_t)wp[0] << 32) | wp[1];
+  uint32_t nextw = wp[2];
+  wp += 3;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) {
+    uint32_t e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if ((4 * d + j) % K == 0) GHF_REFILL();
+      const uint32_t ent = dec_lookup(T, (uint32_t)((W << o) >> 32));
+      o += (ent >> 8) & 0xFFu;
+      e[j] = ent;
+    }
+    acc |= e[0] | e[1] | e[2] | e[3];
+    // byte 0 of four entries -> one dword (v_perm_b32): {a.b0, b.b0} then {lo16, hi16}
+    const uint32_t lo = __builtin_amdgcn_perm(e[1], e[0], 0x0C0C0400u);
+    const uint32_t hi = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0400u);
+    out[d] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+  }
+  used = (uint32_t)(wp - wp0 - 3) * 32u + o - o0;
+  return acc;
+}
+
+// HOT, small alphabet (2 * max_len <= 10): any two codes fit lut2's index, so one lookup yields two symbols and the serial
+// shift -> lookup -> add chain is half as long.  Three lookups (<= 30 bits) per refill check.
+// entry = sym0 | sym1 << 8 | (len0 + len1) << 16 | bit 30: not two data symbols
+__device__ __forceinline__ uint32_t dec_hot_pair(const uint32_t* in, const DecLut& T2, uint32_t pos, uint32_t (&out)[16], uint32_t& used) {
+  const uint32_t* wp = in + (pos >> 5);
+  const uint32_t* const wp0 = wp;
+  uint32_t o = pos & 31u;
+  const uint32_t o0 = o;
+  uint64_t W = ((uint64_t)wp[0] << 32) | wp[1];
+  uint32_t nextw = wp[2];
+  wp += 3;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) {
+    uint32_t e[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if ((2 * d + j) % 3 == 0) GHF_REFILL();
+      const uint32_t ent = dec_lookup(T2, (uint32_t)((W << o) >> 32));
+      o += (ent >> 16) & 0xFFu;
+      e[j] = ent;
+    }
+    acc |= e[0] | e[1];
+    out[d] = __builtin_amdgcn_perm(e[1], e[0], 0x05040100u);  // {a.sym0, a.sym1, b.sym0, b.sym1}
+  }
+  used = (uint32_t)(wp - wp0 - 3) * 32u + o - o0;
+  return acc;
+}
+
+// HOT for codes beyond the direct table (max_len > 12; no BASELINE config): the reference's linear extension on a miss,
+// four output bytes per store, straight to HBM.
+template <int K>
+__device__ __forceinline__ uint32_t dec_hot_long(const DecLds7& L, const uint32_t* in, const DecLut& T, int lut_bits, int max_len,
+                                                 uint32_t pos, uint8_t* optr, uint32_t& used) {
+  const uint32_t* wp = in + (pos >> 5);
+  const uint32_t* const wp0 = wp;
+  uint32_t o = pos & 31u;
+  const uint32_t o0 = o;
+  uint64_t W = ((uint64_t)wp[0] << 32) | wp[1];
+  uint32_t nextw = wp[2];
+  wp += 3;
+  uint32_t acc = 0;
+#pragma unroll 1
+  for (int d = 0; d < 16; ++d) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j % K == 0) GHF_REFILL();
+      const uint32_t v = (uint32_t)((W << o) >> 32);
+      uint32_t ent = dec_lookup(T, v);
+      if (__builtin_expect((ent & kEntNone) != 0, 0)) ent = dec_long_entry(L, v, lut_bits, max_len);
+      o += (ent >> 8) & 0xFFu;
+      acc |= ent;
+      w |= (ent & 0xFFu) << (8 * j);
+    }
+    reinterpret_cast<uint32_t*>(optr)[d] = w;
+  }
+  used = (uint32_t)(wp - wp0 - 3) * 32u + o - o0;
+  return acc;
+}
+#undef GHF_REFILL
+
+// COLD: whatever the hot passes do not take -- the stream's last group (ragged, followed by the end mark), spans that do
+// not fit the LDS tile (read from memory), unaligned output.  One symbol at a time, one byte per store.
+template <bool STAGED>
+__device__ __forceinline__ uint32_t dec_cold(const DecLds7& L, const DecIn<STAGED>& I, const DecLut& T, int lut_bits, int max_len,
+                                             uint64_t pos, uint32_t cnt, bool valid, uint8_t* optr, int has_next,
+                                             uint64_t expect_bits) {
+  if (!valid) return 0u;
+  uint32_t widx = (uint32_t)(pos >> 5);
+  uint32_t o = (uint32_t)(pos & 31u);
+  const uint32_t o0 = o, widx0 = widx;
+  uint64_t W = ((uint64_t)I.fetch(widx) << 32) | I.fetch(widx + 1);
+  uint32_t nextw = I.fetch(widx + 2);
+  widx += 3;
+  uint32_t acc = 0;
+  auto one = [&]() -> uint32_t {
+    if (o >= 32u) {
+      W = (W << 32) | nextw;
+      o -= 32u;
+      nextw = I.fetch(widx++);
+    }
+    const uint32_t v = (uint32_t)((W << o) >> 32);
+    uint32_t ent = dec_lookup(T, v);
+    if (ent & kEntNone) ent = dec_long_entry(L, v, lut_bits, max_len);
+    o += (ent >> 8) & 0xFFu;
+    return ent;
+  };
+  for (uint32_t i = 0; i < cnt; ++i) {
+    const uint32_t ent = one();
+    acc |= ent;
+    optr[i] = (uint8_t)ent;
+  }
+  // the index says where the next segment starts: an end-to-end check of every segment
+  if (has_next == 1) {
+    const uint64_t used = (uint64_t)(widx - widx0 - 3) * 32 + o - o0;
+    if (used != expect_bits) acc |= kEntNone;
+  } else if (has_next == 0) {
+    if (!(one() & kEntEnd)) acc |= kEntNone;  // canonical_huff_encoder.cc:404: the end mark must follow
+  }
+  return acc;
+}
+
+// K7.  Persistent waves; each pass a wave takes one side-car block = 64 consecutive segments (4096 symbols):
+//   1. the compressed span of the block (known from the side-car) is copied into LDS with coalesced 16-byte loads,
+//      byte-swapped to big-endian words;
+//   2. every lane decodes its 64 symbols from a 64-bit window: one LDS table lookup per symbol, the 64 bytes stay in
+//      registers;
+//   3. the wave's 4 KiB of output go through the (now dead) input tile and leave as four coalesced 1 KiB stores.
+// The loop is software-pipelined over groups so that no HBM latency is exposed: while group i is decoded,
+// the span of group i+1 is in flight into registers and the side-car entries of group i+2 are in flight too.
+struct DecMeta {   // side-car words of one group, as loaded: issued a whole pass before they are combined, and nothing in
+  uint64_t blk;    // between may need their values (a dependent use right behind the loads would make the compiler wait
+  uint32_t end;    // for every older memory operation, including the span prefetch).  blk = block start (same word in
+};                 // every lane), end = where MY segment ends, relative to blk
+
+struct DecGroup {  // one group, ready to be decoded
+  uint64_t byte0;  // uniform: first staged byte (16-aligned)
+  uint32_t span;   // uniform: staged bytes
+  uint32_t pos;    // bit of the staged span at which my segment starts
+  uint32_t expect; // bits of my segment
+  bool bad;        // my side-car words are implausible
+};
+
+__device__ __forceinline__ void dec_issue_meta(const DecParams& P, uint64_t group, int lane, DecMeta& M) {
+  const uint64_t last = P.n_segs - 1;
+  const uint64_t seg = group * 64 + lane;
+  M.blk = P.chunk_bit[group];
+  M.end = P.seg_bit[seg < last ? seg : last];  // clamped: unconditional loads
+}
+
+__device__ __forceinline__ void dec_group(const DecParams& P, uint64_t group, int lane, int max_len, const DecMeta& M, DecGroup& G) {
+  const uint64_t stream_end_bit = P.stream_bytes * 8;
+  const uint64_t seg0 = group * 64;
+  const bool valid = seg0 + lane < P.n_segs;
+  const uint64_t B0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(M.blk >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)M.blk);
+  // my segment starts where my left neighbour's ends (v_mov_dpp wave_shr:1; lane 0 starts with the block)
+  const uint32_t start = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)M.end, 0x138, 0xF, 0xF, true);
+  uint64_t B1 = B0 + (uint32_t)__builtin_amdgcn_readlane((int)M.end, 63);
+  if (seg0 + 64 >= P.n_segs) {
+    // last group: bound it by its last segment's worst case (+ end mark) rather than by a side-car word
+    uint32_t m = valid ? start + 65u * (uint32_t)max_len : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t o = __shfl_xor(m, d, 64);
+      m = o > m ? o : m;
+    }
+    B1 = B0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+  }
+  if (B1 > stream_end_bit) B1 = stream_end_bit;
+  G.byte0 = (B0 >> 3) & ~15ull;
+  uint64_t byte1 = ((B1 + 7) >> 3) + 12;  // window look-ahead
+  if (byte1 > P.stream_bytes) byte1 = P.stream_bytes;
+  if (G.byte0 > byte1) G.byte0 = byte1 & ~15ull;  // corrupt side-car: caught by `bad`
+  const uint64_t span = byte1 - G.byte0;
+  G.span = span > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)span;
+  G.pos = (uint32_t)(B0 & 127u) + start;
+  G.expect = M.end - start;
+  G.bad = valid && (M.end < start || B0 + M.end > stream_end_bit || B0 >= stream_end_bit);
+}
+
+constexpr int kDecVec = (kDec7InBytes + 1023) / 1024;  // 16-byte vectors per lane that cover a staged span
+
+__global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
+  __shared__ DecLds7 L;
+  const int tid = threadIdx.x;
+  if (tid == 0) L.status0 = *P.status;  // one read per workgroup: the exit must be uniform
+  __syncthreads();
+  if (L.status0 != 0) return;
+  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
+  dec_lds_load7(L, P.dt, tid, kDec7Threads);
+  __syncthreads();
+  const int pair_bits = P.dt->pair_bits;
+  const int lane = tid & 63;
+  // this lane's replicas: T1 = one symbol per lookup, T2 = two (small alphabets only)
+  DecLut T1, T2;
+  {
+    const int r1 = pair_bits ? 5 : ((kDec7LutLog2 - lut_bits) < 5 ? (kDec7LutLog2 - lut_bits) : 5);
+    const uint32_t* t1 = L.lut + (pair_bits ? kDec7LutSlots : 0);
+    T1.base = reinterpret_cast<const char*>(t1 + ((uint32_t)lane & ((1u << r1) - 1u)));
+    T1.lsh = 32 - lut_bits;
+    T1.ash = r1 + 2;
+    const int r2 = (kDec7LutLog2 - pair_bits) < 5 ? (kDec7LutLog2 - pair_bits) : 5;
+    T2.base = reinterpret_cast<const char*>(L.lut + ((uint32_t)lane & ((1u << r2) - 1u)));
+    T2.lsh = 32 - pair_bits;
+    T2.ash = r2 + 2;
+  }
+  if (blockIdx.x == 0 && tid == 0 && P.out_bytes) *P.out_bytes = P.n_symbols;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar loop control
+  const uint64_t ngroups = (P.n_segs + 63) >> 6;
+  const uint64_t full_bytes = P.stream_bytes & ~15ull;  // whole 16-byte vectors of the stream
+  const bool out_aligned = (((uintptr_t)P.out) & 15u) == 0;
+  uint32_t* in = L.in[wave];
+  uint32_t bad_acc = 0;
+  // groups are handed out by a global ticket counter, not by a fixed stride: a wave that starts late (e.g. because
+  // another kernel occupied its CU) simply takes fewer groups instead of becoming the kernel's straggler
+  const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;  // every class needs at least one workgroup
+  const uint32_t cls = blockIdx.x % ncls;
+  auto ticket_issue = [&]() -> unsigned int {  // the atomic's return value stays in a VGPR until ticket_group() needs it
+    unsigned int t = 0;
+    if (lane == 0) t = atomicAdd(&P.dt->ticket[cls * 32], 1u);
+    return t;
+  };
+  // every wave's first three groups are fixed (no round trip to a counter before the first load can be issued: three
+  // dependent atomics on 16 counters cost the 4096 waves several microseconds of start-up); tickets number the rest
+  const uint64_t nwaves = (uint64_t)gridDim.x * kDec7Waves;
+  const uint64_t wid = (uint64_t)blockIdx.x * kDec7Waves + (uint64_t)wave;
+  auto ticket_group = [&](unsigned int t) -> uint64_t {
+    return 3 * nwaves + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * ncls + cls;
+  };
+  uint64_t group = wid;
+  if (group >= ngroups) return;
+  uint64_t g1 = wid + nwaves, g2 = wid + 2 * nwaves;  // this wave's next two groups
+  const uint64_t glast = ngroups - 1;
+  auto clampg = [&](uint64_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
+
+  // issue the 16-byte loads of a group's span (vector k of this lane = bytes byte0 + k*1024 + lane*16 ..)
+  auto vec_ok = [&](const DecGroup& G, int k, int lane) -> bool {
+    const uint32_t o = (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+    const uint64_t room = full_bytes - G.byte0;  // byte0 <= full_bytes whenever span > 0 matters; else no lane is ok
+    return o < G.span && G.byte0 <= full_bytes && (uint64_t)o + 16 <= room;
+  };
+  auto issue = [&](const DecGroup& G, uint4 (&R)[kDecVec], int lane) {
+    const uint8_t* base = P.stream + G.byte0 + (uint32_t)lane * 16u;
+#pragma unroll
+    for (int k = 0; k < kDecVec; ++k)  // lanes behind the span re-read byte 0 (an L2 hit)
+      R[k] = *reinterpret_cast<const uint4*>(vec_ok(G, k, lane) ? base + k * 1024 : P.stream);
+  };
+
+  // one instantiation of the whole loop per decoder variant: the hot pass then holds ONE straight-line decoder
+  auto run = [&](auto var_tag) {
+    DecGroup cur, nxt;
+    uint4 R[kDecVec];
+    DecMeta M;  // raw side-car words of the group after `cur` (of the one after that once the pass has issued its loads)
+    dec_issue_meta(P, group, lane, M);
+    dec_group(P, group, lane, max_len, M, cur);
+    issue(cur, R, lane);
+    dec_issue_meta(P, clampg(g1), lane, M);
+
+    // One pass over a group.  HOT = the group is complete, staged, plausible and not the stream's last: the body then has
+    // no data-dependent branch around its memory operations, so the compiler can count them -- the wait for the
+    // prefetched span becomes "all but the youngest four" (this group's output stores) instead of vmcnt(0), and the wave
+    // no longer sleeps until its own stores are acknowledged by L2 (which is what bounded this kernel in round 1).
+    auto pass = [&](auto hot_tag, auto var_tag) {
+      constexpr bool HOT = decltype(hot_tag)::value;
+      constexpr int VAR = decltype(var_tag)::value;
+      // the lane number, opaque to the optimiser: everything derived from it below (a dozen LDS and global addresses) is
+      // recomputed per pass with a few VALU instructions instead of being hoisted out of the loop and then spilled
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      // ---- 1. this group's span: registers -> LDS (big-endian words); everything behind it reads as zero
+      wave_sync();
+  #pragma unroll
+      for (int k = 0; k < kDecVec; ++k) {
+        const uint32_t o = (uint32_t)k * 1024u + (uint32_t)ln * 16u;
+        uint4 v = R[k];
+        v = vec_ok(cur, k, ln) ? make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)) : make_uint4(0, 0, 0, 0);
+        if ((k + 1) * 1024 <= kDec7InBytes || o < (uint32_t)kDec7InBytes) *reinterpret_cast<uint4*>(in + (o >> 2)) = v;
+      }
+      if (ln < 4) in[kDec7InWords + ln] = 0;
+      if (!HOT && cur.byte0 + cur.span > full_bytes && full_bytes >= cur.byte0 && ln == 0) {
+        // the stream's last, incomplete 16 bytes: byte loads, never past the end of the buffer
+        uint32_t q[4] = {0, 0, 0, 0};
+        for (uint64_t j = 0; full_bytes + j < P.stream_bytes; ++j) q[j >> 2] |= (uint32_t)P.stream[full_bytes + j] << (24 - 8 * (j & 3));
+        const uint64_t w = (full_bytes - cur.byte0) >> 2;
+        if (w + 3 < (uint64_t)kDec7InWords + 4) {
+          in[w] = q[0]; in[w + 1] = q[1]; in[w + 2] = q[2]; in[w + 3] = q[3];
+        }
+      }
+      wave_sync();
+      // ---- prefetch: span of the next group (its side-car entries arrived during the last decode), side-car of the one after
+      dec_group(P, clampg(g1), ln, max_len, M, nxt);
+      issue(nxt, R, ln);
+      dec_issue_meta(P, clampg(g2), ln, M);
+      const unsigned int t3 = ticket_issue();  // resolved after the decode
+      // ---- 2. decode
+      const uint64_t seg0 = group * 64;
+      const uint64_t seg = seg0 + ln;
+      const uint64_t sym0 = seg * kSegSymbols;
+      if (HOT) {
+        uint32_t used, acc;
+        if (VAR <= 3) {
+          uint32_t out[16];
+          // K = 33 / max_len symbols per refill check
+          if (VAR == 0) acc = dec_hot_pair(in, T2, cur.pos, out, used) >> 14;  // bit 30 -> bit 16
+          else if (VAR == 1) acc = dec_hot<4>(in, T1, cur.pos, out, used);
+          else if (VAR == 2) acc = dec_hot<3>(in, T1, cur.pos, out, used);
+          else acc = dec_hot<2>(in, T1, cur.pos, out, used);
+          // ---- 3. copy-out through the input tile (dead now): ln-major 64-byte rows, pieces XOR-swizzled so that the 16
+          // lanes of a write phase hit 16 different bank groups; then four fully coalesced 1 KiB stores per wave,
+          // straight-line, so that the compiler can count them
+          wave_sync();
+          const uint32_t osw = ((uint32_t)ln >> 2) & 3u;
+  #pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<uint4*>(in + ln * 16 + (((uint32_t)q ^ osw) << 2)) = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+          wave_sync();
+          uint8_t* og = P.out + seg0 * kSegSymbols + (uint32_t)ln * 16;
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t sl = (uint32_t)r * 16 + ((uint32_t)ln >> 2);  // the ln whose row holds my piece
+            const uint32_t piece = ((uint32_t)ln & 3u) ^ ((sl >> 2) & 3u);
+            *reinterpret_cast<uint4*>(og + r * 1024) = *reinterpret_cast<const uint4*>(in + sl * 16 + piece * 4);
+          }
+        } else if (VAR == 4) {
+          acc = dec_hot_long<2>(L, in, T1, lut_bits, max_len, cur.pos, P.out + sym0, used);
+        } else {
+          acc = dec_hot_long<1>(L, in, T1, lut_bits, max_len, cur.pos, P.out + sym0, used);
+        }
+        if (used != cur.expect) acc |= kEntNone;
+        bad_acc |= acc;
+      } else {
+        const bool valid = seg < P.n_segs;
+        if (__ballot(cur.bad)) {
+          if (cur.bad) latch_status(P.status, GHF_E_CORRUPT);
+        } else {
+          const bool staged = cur.span <= (uint32_t)kDec7InBytes;
+          uint32_t cnt = 0;
+          if (valid) cnt = (P.n_symbols - sym0 >= (uint64_t)kSegSymbols) ? (uint32_t)kSegSymbols : (uint32_t)(P.n_symbols - sym0);
+          // 1: the side-car says where the next segment starts; 0: the end mark must follow; 2: nothing to check
+          const int has_next = seg + 1 < P.n_segs ? 1 : (P.no_end_mark ? 2 : 0);
+          const uint8_t* src = P.stream + cur.byte0;
+          if (staged) {
+            DecIn<true> I{in, src, cur.span};
+            bad_acc |= dec_cold<true>(L, I, T1, lut_bits, max_len, cur.pos, cnt, valid, P.out + sym0, has_next, cur.expect);
+          } else {
+            DecIn<false> I{in, src, cur.span};
+            bad_acc |= dec_cold<false>(L, I, T1, lut_bits, max_len, cur.pos, cnt, valid, P.out + sym0, has_next, cur.expect);
+          }
+        }
+      }
+      // ---- rotate (all of these values have long arrived)
+      cur = nxt;
+      group = g1;
+      g1 = g2;
+      g2 = ticket_group(t3);
+    };
+    auto is_hot = [&]() -> bool {  // wave-uniform
+      if (group + 1 >= ngroups || !out_aligned) return false;                   // the last group may be ragged / carries the end mark
+      if (cur.span > (uint32_t)kDec7InBytes || cur.byte0 + cur.span > full_bytes) return false;
+      return __ballot(cur.bad) == 0;
+    };
+    while (group < ngroups) {
+      if (is_hot()) {
+        // drain once on entry: the hot loop's waits are then computed from its own back edge alone (exact counts)
+        // instead of being merged with whatever the cold paths left outstanding
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        do pass(std::true_type{}, var_tag);
+        while (is_hot());
+      }
+      if (group < ngroups) pass(std::false_type{}, var_tag);
+    }
+  };
+  if (pair_bits) run(std::integral_constant<int, 0>{});
+  else if (max_len <= 8) run(std::integral_constant<int, 1>{});
+  else if (max_len <= 11) run(std::integral_constant<int, 2>{});
+  else if (max_len <= kDecLutBitsMax) run(std::integral_constant<int, 3>{});
+  else if (max_len <= 16) run(std::integral_constant<int, 4>{});
+  else run(std::integral_constant<int, 5>{});
+  if (bad_acc & (kEntEnd | kEntNone)) latch_status(P.status, GHF_E_CORRUPT);  // 64 data symbols per full segment, always
+}
+
+void launch_decode(const DecParams& p, hipStream_t s) {
+  const uint64_t groups = (p.n_segs + 63) / 64;
+  uint64_t blocks = (groups + kDec7Waves - 1) / kDec7Waves;
+  if (blocks == 0) return;
+  if (blocks > 256) blocks = 256;  // persistent: one workgroup of 16 waves per CU (its LDS tiles + table take 146 KiB)
+  hipLaunchKernelGGL(k_decode, dim3((uint32_t)blocks), dim3(kDec7Threads), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: rebuild the side-car of a FOREIGN stream (a .crs2 written by the reference has no sync points).
+// Huffman codes self-synchronise: a decoder started at a wrong bit falls into step with the true
+// code boundaries after a few symbols.  The body is cut into 512-bit subsequences; every thread decodes
+// its subsequence from its current guess of the first code boundary and tells its right neighbour where
+// it landed.  Thread 0 starts at a true boundary, so the fixed point of this iteration is the true
+// segmentation; passes repeat (only threads whose guess changed redo work) until nothing changes.
+// Then symbol counts are prefix-summed, the end mark fixes n, and one more pass writes the bit position
+// of every 64th symbol -- the same side-car K5 emits.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSubBits = 512;
+
+struct BitReader {  // left-justified 64-bit window over big-endian words (LDS)
+  const uint32_t* in;
+  uint32_t widx;
+  uint64_t window;
+  int avail;
+  __device__ __forceinline__ void init(const uint32_t* words, uint64_t pos) {
+    in = words;
+    widx = (uint32_t)(pos >> 5);
+    const uint32_t off = (uint32_t)(pos & 31u);
+    window = (((uint64_t)in[widx] << 32) | in[widx + 1]) << off;
+    widx += 2;
+    avail = 64 - (int)off;
+  }
+  __device__ __forceinline__ uint32_t hi() {
+    if (avail < 32) {
+      window |= (uint64_t)in[widx++] << (32 - avail);
+      avail += 32;
+    }
+    return (uint32_t)(window >> 32);
+  }
+  __device__ __forceinline__ void skip(uint32_t len) {
+    window <<= len;
+    avail -= (int)len;
+  }
+};
+
+__device__ __forceinline__ uint32_t dec_any(const DecLds& L, uint32_t hi, int lut_bits, int max_len, uint32_t& len) {
+  const uint32_t ent = L.lut[hi >> (32 - lut_bits)];
+  len = ent >> 9;
+  if (len) return ent & 0x1FFu;
+  const uint32_t r = dec_long(L, hi, lut_bits, max_len);
+  len = r >> 16;
+  return r & 0xFFFFu;
+}
+
+// stage the bits of 64 consecutive subsequences (+ look-ahead) of the body into this wave's LDS words;
+// returns the bit offset of subsequence `sub0` inside the staged words
+__device__ __forceinline__ uint64_t stage_subs(const SyncParams& P, uint64_t sub0, uint32_t* in, int lane) {
+  const uint64_t bit0 = P.body_bit0 + sub0 * kSubBits;
+  const uint64_t byte0 = (bit0 >> 3) & ~15ull;
+  uint64_t byte1 = ((bit0 + 64ull * kSubBits + 7) >> 3) + 16;
+  if (byte1 > P.stream_bytes) byte1 = P.stream_bytes;
+  const uint64_t span = byte1 > byte0 ? byte1 - byte0 : 0;
+  const uint8_t* src = P.stream + byte0;
+  for (uint64_t o = (uint64_t)lane * 16; o < span; o += 1024) {
+    uint4 v;
+    if (o + 16 <= span) {
+      v = *reinterpret_cast<const uint4*>(src + o);
+    } else {
+      uint32_t q[4] = {0, 0, 0, 0};
+      for (uint32_t j = 0; o + j < span; ++j) q[j >> 2] |= (uint32_t)src[o + j] << (8 * (j & 3));
+      v = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+    *reinterpret_cast<uint4*>(in + (o >> 2)) = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+  }
+  const uint32_t wend = (uint32_t)((span + 15) >> 4) << 2;
+  for (uint32_t k = wend + lane; k < (uint32_t)kDecInWords + 4; k += 64) in[k] = 0;
+  return bit0 - byte0 * 8;
+}
+
+__global__ __launch_bounds__(kDecThreads) void k_sync_pass(SyncParams P) {
+  __shared__ DecLds L;
+  const int tid = threadIdx.x;
+  dec_lds_load(L, P.dt, tid, kDecThreads);
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
+  const uint64_t ngroups = (P.nsub + 63) >> 6;
+  const uint64_t body_bits = P.end_bit - P.body_bit0;
+  uint32_t* in = L.in[wave];
+  for (uint64_t g = (uint64_t)blockIdx.x * kDecWaves + wave; g < ngroups; g += (uint64_t)gridDim.x * kDecWaves) {
+    const uint64_t sub = g * 64 + lane;
+    const bool valid = sub < P.nsub;
+    uint32_t st = 0;
+    bool work = false;
+    if (valid) {
+      st = P.start[sub];
+      work = P.used[sub] != st;
+    }
+    if (!__ballot(work)) continue;  // the whole wave's results are still current
+    wave_sync();
+    const uint64_t base = stage_subs(P, g * 64, in, lane);
+    wave_sync();
+    if (work) {
+      const uint64_t sub_lo = (uint64_t)lane * kSubBits;  // relative to the wave's first subsequence
+      const uint64_t sub_hi = sub_lo + kSubBits;
+      const uint64_t limit = body_bits - g * 64 * kSubBits;  // end of the stream, same origin
+      uint64_t pos = sub_lo + st;
+      uint32_t count = 0;
+      bool eof = false;
+      BitReader br;
+      br.init(in, base + pos);
+      while (pos < sub_hi && pos < limit) {
+        uint32_t len;
+        const uint32_t sym = dec_any(L, br.hi(), lut_bits, max_len, len);
+        if (sym == 256u) {
+          eof = true;
+          break;
+        }
+        br.skip(len);
+        pos += len;
+        ++count;
+      }
+      // .crs has no end mark: "eof" then means "this cannot be right" -- a bit pattern that is no code, or a last
+      // code that runs past the end of the stream
+      if (P.no_eof == 1u && pos > limit) eof = true;
+      P.cnt[sub] = count;
+      P.eof[sub] = eof ? 1 : 0;
+      P.used[sub] = (uint16_t)st;
+      if (!eof && pos >= sub_hi && sub + 1 < P.nsub) {
+        const uint16_t land = (uint16_t)(pos - sub_hi);
+        if (P.start[sub + 1] != land) {
+          P.start[sub + 1] = land;
+          *P.changed = 1;
+        }
+      }
+      // a PIECE of a stream (mode 2, multi-GPU decode): the last code may run into the next piece's bytes (they are
+      // there as look-ahead); where it ends is the next piece's first code boundary
+      if (P.no_eof == 2u && sub + 1 == P.nsub) P.start[P.nsub] = eof ? (uint16_t)0xFFFF : (uint16_t)(pos - limit);
+    }
+  }
+}
+
+// first subsequence that holds the end mark (valid once the passes have converged)
+__global__ __launch_bounds__(256) void k_sync_eof(SyncParams P) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < P.nsub && P.eof[i]) atomicMin(reinterpret_cast<unsigned long long*>(P.eof_sub), (unsigned long long)i);
+}
+
+// symbols per tile of 256 subsequences, nothing counted behind the end mark
+__global__ __launch_bounds__(256) void k_sync_tile_sums(SyncParams P) {
+  __shared__ unsigned long long ws[4];
+  const uint64_t eof_sub = *P.eof_sub;
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long v = (i < P.nsub && i <= eof_sub) ? P.cnt[i] : 0ull;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) P.tile_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// absolute bit position of every 64th symbol (the side-car's granularity)
+__global__ __launch_bounds__(kDecThreads) void k_sync_index(SyncParams P, uint64_t* __restrict__ seg_abs, uint64_t n_segs, uint64_t n_symbols) {
+  __shared__ DecLds L;
+  __shared__ unsigned long long wsum[kDecWaves];
+  const int tid = threadIdx.x;
+  dec_lds_load(L, P.dt, tid, kDecThreads);
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
+  const uint64_t eof_sub = *P.eof_sub;
+  const uint64_t sub = (uint64_t)blockIdx.x * 256 + tid;  // one tile of 256 subsequences per workgroup
+  const bool valid = sub < P.nsub && sub <= eof_sub;
+  const uint32_t c = valid ? P.cnt[sub] : 0u;
+  // exclusive prefix of the symbol counts inside the tile
+  unsigned long long incl = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned long long first = P.tile_sum[blockIdx.x] + incl - c;  // tile_sum[] holds the exclusive scan by now
+  for (int k = 0; k < wave; ++k) first += wsum[k];
+  const uint64_t g = (uint64_t)blockIdx.x * kDecWaves + wave;
+  uint32_t* in = L.in[wave];
+  if (g * 64 >= P.nsub) return;
+  const uint64_t base = stage_subs(P, g * 64, in, lane);
+  wave_sync();
+  if (!valid) return;
+  const uint64_t body_bits = P.end_bit - P.body_bit0;
+  const uint64_t sub_lo = (uint64_t)lane * kSubBits;
+  const uint64_t limit = body_bits - g * 64 * kSubBits;
+  uint64_t pos = sub_lo + P.start[sub];
+  BitReader br;
+  br.init(in, base + pos);
+  const uint64_t abs0 = P.body_bit0 + g * 64 * kSubBits;  // stream bit of the wave's first subsequence
+  for (uint32_t k = 0; k < c && pos < limit; ++k) {
+    const uint64_t sidx = first + k;
+    if ((sidx & 63u) == 0 && (sidx >> 6) < n_segs) seg_abs[sidx >> 6] = abs0 + pos;
+    uint32_t len;
+    (void)dec_any(L, br.hi(), lut_bits, max_len, len);
+    br.skip(len);
+    pos += len;
+  }
+  if (c && first + c == n_symbols) seg_abs[n_segs] = abs0 + pos;  // where the last data symbol ends
+}
+
+// seg_abs[s] = stream bit of symbol 64 s (s < n_segs), seg_abs[n_segs] = end of the last symbol  ->  the side-car K5 emits:
+// absolute start bit per block of 64 segments, end bit of every segment relative to its block
+__global__ __launch_bounds__(256) void k_sync_finalize(const uint64_t* __restrict__ seg_abs, uint64_t n_segs,
+                                                       uint64_t* __restrict__ chunk_bit, uint32_t* __restrict__ seg_bit) {
+  const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_segs) return;
+  const uint64_t b = s / (kBlockSymbols / kSegSymbols);
+  const uint64_t b0 = seg_abs[b * (kBlockSymbols / kSegSymbols)];
+  if (s == b * (kBlockSymbols / kSegSymbols)) chunk_bit[b] = b0;
+  seg_bit[s] = (uint32_t)(seg_abs[s + 1] - b0);
+}
+
+void launch_sync_pass(const SyncParams& p, hipStream_t s) {
+  const uint64_t groups = (p.nsub + 63) / 64;
+  uint64_t blocks = (groups + kDecWaves - 1) / kDecWaves;
+  if (blocks > 256 * 5) blocks = 256 * 5;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_sync_pass, dim3((uint32_t)blocks), dim3(kDecThreads), 0, s, p);
+}
+void launch_sync_counts(const SyncParams& p, uint64_t* d_total, hipStream_t s) {
+  const uint32_t tiles = (uint32_t)((p.nsub + 255) / 256);
+  hipLaunchKernelGGL(k_sync_eof, dim3(tiles), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_sync_tile_sums, dim3(tiles), dim3(256), 0, s, p);
+  launch_scan(p.tile_sum, tiles, d_total, s);
+}
+void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_symbols, uint64_t* d_chunk_bit, uint32_t* d_seg_bit,
+                       hipStream_t s) {
+  const uint64_t n_segs = (n_symbols + kSegSymbols - 1) / kSegSymbols;
+  const uint32_t tiles = (uint32_t)((p.nsub + 255) / 256);
+  hipLaunchKernelGGL(k_sync_index, dim3(tiles), dim3(kDecThreads), 0, s, p, d_seg_abs, n_segs, n_symbols);
+  if (n_segs) hipLaunchKernelGGL(k_sync_finalize, dim3((uint32_t)((n_segs + 255) / 256)), dim3(256), 0, s, d_seg_abs, n_segs,
+                                 d_chunk_bit, d_seg_bit);
+}
+
+}  // namespace ghf

@@ -50,25 +50,27 @@ __device__ __forceinline__ void deposit64(uint32_t* flat, uint32_t p, uint64_t q
 // and retires the old stores while tile t+2 stays in flight, and the compiler derives no wait of its own from a
 // store count it would have to guess.
 template <int NI, bool DRAIN>
-__device__ __forceinline__ uint32_t emit_items(WaveOut& W, const uint64_t (&q)[NI], const uint32_t (&l)[NI], int lane,
-                                               uint32_t* seg_dst, uint32_t seg_base) {
-  uint32_t T = 0;
+__device__ __forceinline__ uint32_t emit_items(WaveOut& W, const uint64_t (&q)[NI], const uint32_t (&l)[NI], bool mine, int lane,
+                                               uint32_t* seg_dst, uint32_t seg_base, uint64_t* blk_dst, uint64_t blk_val) {
+  uint32_t T = 0;  // mine == false: this lane sits the pass out (its items count as empty)
 #pragma unroll
   for (int i = 0; i < NI; ++i) T += l[i];
+  if (!mine) T = 0;
   const uint32_t incl = wave_incl_scan_u32(T);
   const uint32_t excl = incl - T;
   const uint32_t total = wave_last_u32(incl);
   uint32_t p = W.bit0 + W.carry + excl;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    deposit64(W.flat, p, q[i], l[i]);
+    deposit64(W.flat, p, mine ? q[i] : 0ull, mine ? l[i] : 0u);
     p += l[i];
   }
   wave_sync();
   const uint32_t endbits = W.carry + total;
   const uint32_t U = endbits >> 7;  // <= 128
   if (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F71);  // vmcnt(1)
-  if (seg_dst) *seg_dst = seg_base + excl;
+  if (seg_dst) *seg_dst = seg_base + incl;  // side-car: where this lane's segment ends, relative to its block
+  if (blk_dst) *blk_dst = blk_val;          // side-car: where the block begins (one lane, every fourth tile)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const uint32_t j = (uint32_t)lane + 64u * h;
@@ -167,24 +169,17 @@ struct EmitMode<true> {
 template <bool WIDE, bool DRAIN>
 __device__ __forceinline__ uint32_t emit_tile(WaveOut& W, const uint64_t (&q)[EmitMode<WIDE>::NI],
                                               const uint32_t (&l)[EmitMode<WIDE>::NI], int lane, uint32_t* seg_out,
-                                              bool seg_valid, uint32_t relbits) {
+                                              bool seg_valid, uint32_t relbits, uint64_t* blk_dst, uint64_t blk_val) {
   constexpr int NI = EmitMode<WIDE>::NI;
-  uint32_t* const seg_dst = (seg_out && seg_valid && (lane & 3) == 0) ? seg_out : nullptr;  // stored with the tile's units
+  uint32_t* const seg_dst = (seg_out && seg_valid && (lane & 3) == 3) ? seg_out : nullptr;  // stored with the tile's units
   if (!WIDE) {
-    return emit_items<NI, DRAIN>(W, q, l, lane, seg_dst, relbits);
+    return emit_items<NI, DRAIN>(W, q, l, true, lane, seg_dst, relbits, blk_dst, blk_val);
   } else {
     uint32_t total = 0;
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
       const bool mine = (lane >> 5) == h;
-      uint64_t qq[NI];
-      uint32_t ll[NI];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        qq[i] = mine ? q[i] : 0ull;
-        ll[i] = mine ? l[i] : 0u;
-      }
-      total += emit_items<NI, false>(W, qq, ll, lane, mine ? seg_dst : nullptr, relbits + total);
+      total += emit_items<NI, false>(W, q, l, mine, lane, mine ? seg_dst : nullptr, relbits + total, h == 0 ? blk_dst : nullptr, blk_val);
     }
     return total;
   }
@@ -215,7 +210,6 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
   W.unit_base = (Pc >> 7) - (G.origin_byte >> 4);
   W.carry = (uint32_t)(Pc & 127u);
   for (int i = lane; i < kStageWords / 4; i += 64) reinterpret_cast<uint4*>(st)[i] = make_uint4(0, 0, 0, 0);
-  if (lane == 0 && P.chunk_bit) P.chunk_bit[c] = Pc - G.origin_byte * 8;  // relative to d_out[0]
   wave_sync();
 
   // ---- the bits in front of this chunk's first code that share its first 16-byte unit
@@ -265,7 +259,17 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
       reinterpret_cast<uint32_t*>(P.out)[w] = bswap32(header_word(P.code, w, G.max_len));
   }
 
-  uint32_t relbits = 0;  // bits of this chunk emitted so far (a chunk has at most 2^20 symbols of <= 32 bits)
+  uint32_t relbits = 0;   // bits of this chunk emitted so far (a chunk has at most 2^20 symbols of <= 32 bits)
+  uint32_t blockrel = 0;  // ... since the side-car block (4 tiles = 4096 symbols = 64 segments) began
+  uint64_t* const blockp = P.chunk_bit ? P.chunk_bit + (sym0 / kBlockSymbols) : nullptr;
+  const uint64_t bit_origin = Pc - G.origin_byte * 8;  // the chunk's first code, relative to d_out[0]
+  auto tile_done = [&](uint64_t it, uint32_t total) {  // wave-uniform bookkeeping after tile `it`
+    relbits += total;
+    blockrel = ((it & 3) == 3) ? 0u : blockrel + total;
+  };
+  auto block_dst = [&](uint64_t it) -> uint64_t* {  // stored with the tile's units (after its drain)
+    return (blockp && (it & 3) == 0 && lane == 0) ? blockp + (it >> 2) : nullptr;
+  };
   const uint64_t nfull = aligned ? (nsym / kSymPerIter) : 0;
   const uint4* pv = reinterpret_cast<const uint4*>(pin) + lane;
   uint32_t* const segp = P.seg_bit ? P.seg_bit + ((sym0 + (uint64_t)lane * 16) >> 6) : nullptr;
@@ -285,7 +289,8 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
         uint64_t q[NI];
         uint32_t l[NI];
         M::items(tab, lane, v, 16, q, l);
-        relbits += emit_tile<WIDE, !WIDE>(W, q, l, lane, segp ? segp + it * 16 : nullptr, true, relbits);
+        tile_done(it, emit_tile<WIDE, !WIDE>(W, q, l, lane, segp ? segp + it * 16 : nullptr, true, blockrel, block_dst(it),
+                                             bit_origin + relbits));
       }
       {
         const uint4 v = B;
@@ -294,7 +299,7 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
         uint64_t q[NI];
         uint32_t l[NI];
         M::items(tab, lane, v, 16, q, l);
-        relbits += emit_tile<WIDE, !WIDE>(W, q, l, lane, segp ? segp + (it + 1) * 16 : nullptr, true, relbits);
+        tile_done(it + 1, emit_tile<WIDE, !WIDE>(W, q, l, lane, segp ? segp + (it + 1) * 16 : nullptr, true, blockrel, nullptr, 0));
       }
     }
   }
@@ -309,6 +314,7 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
     uint32_t l[NI];
     bool seg_valid = false;
     uint32_t* seg_out = nullptr;
+    uint64_t* blk = nullptr;
     if (it < niter) {
       const uint64_t sb = it * kSymPerIter;
       const uint64_t rem = nsym - sb;
@@ -324,8 +330,9 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
         v = make_uint4(w[0], w[1], w[2], w[3]);
       }
       M::items(tab, lane, v, cnt, q, l);
-      seg_valid = cnt != 0;
+      seg_valid = rem > (uint64_t)(lane & ~3) * 16;  // my segment has at least one symbol
       seg_out = segp ? segp + it * 16 : nullptr;
+      blk = block_dst(it);
     } else {
       const uint32_t el = P.code->length[GHF_NSYM - 1], ec = P.code->codeword[GHF_NSYM - 1];
       const uint32_t pad = (uint32_t)((0 - (Pc + relbits + el)) & 7u);
@@ -339,7 +346,7 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
         l[0] = el + pad;
       }
     }
-    relbits += emit_tile<WIDE, false>(W, q, l, lane, seg_out, seg_valid, relbits);
+    tile_done(it, emit_tile<WIDE, false>(W, q, l, lane, seg_out, seg_valid, blockrel, blk, bit_origin + relbits));
   }
   // the chunk's last, incomplete unit belongs to the next chunk's wave -- unless this is the buffer's last chunk
   if (c + 1 == P.nchunks && W.carry && lane == 0) {

@@ -11,7 +11,8 @@ namespace ghf {
 constexpr int kWave = 64;               // CDNA wavefront
 constexpr int kSymPerLane = 16;         // one 16-byte vector load = one lane's contiguous symbols
 constexpr int kSymPerIter = kWave * kSymPerLane;  // 1 KiB of input per wave iteration
-constexpr int kSegSymbols = 64;         // side-car granularity (4 lanes)
+constexpr int kSegSymbols = 64;         // side-car granularity (4 lanes of K5, one lane of K7)
+constexpr int kBlockSymbols = 4096;     // side-car block = 64 segments = one K7 group = 4 K5 tiles; absolute bit per block
 constexpr uint32_t kMinChunkLog2 = 12;  // 4 KiB
 constexpr uint32_t kMaxChunkLog2 = 20;  // 1 MiB
 constexpr uint32_t kTargetChunks = 8192;
@@ -72,8 +73,8 @@ struct EmitParams {
   uint64_t cap;
   uint32_t chunk_log2;
   uint32_t nchunks;
-  uint64_t* chunk_bit;  // side-car (may be null)
-  uint32_t* seg_bit;    // side-car (may be null)
+  uint64_t* chunk_bit;  // side-car (may be null): [n / 4096] absolute start bit of every block
+  uint32_t* seg_bit;    // side-car (may be null): [n / 64] end bit of every segment, relative to its block
   int flags;
   int* status;
   uint64_t* d_end;  // may be null
@@ -87,7 +88,6 @@ struct DecParams {
   const uint32_t* seg_bit;
   uint64_t n_symbols;
   uint64_t n_segs;
-  uint32_t chunk_log2;
   uint32_t no_end_mark;  // the last symbol is not followed by the end mark (a shard that is not the stream's last)
   uint8_t* out;
   uint64_t* out_bytes;  // optional device u64 <- n_symbols
@@ -117,8 +117,8 @@ struct SyncParams {
 // kernel launchers (ghf_kernels.hip); all asynchronous on `s`
 void launch_sync_pass(const SyncParams& p, hipStream_t s);
 void launch_sync_counts(const SyncParams& p, uint64_t* d_total, hipStream_t s);
-void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_segs, uint32_t chunk_log2, uint64_t* d_chunk_bit,
-                       uint32_t* d_seg_bit, hipStream_t s);
+void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_symbols, uint64_t* d_chunk_bit, uint32_t* d_seg_bit,
+                       hipStream_t s);
 // K1 scratch, all zero between launches: 32 replicas of the 256 totals, the arrival counter (word 8192), 16 ticket
 // counters (word 8208 + 16 k, one 128-byte line each)
 constexpr size_t kHistAccWords = 32 * 256 + 16 + 16 * 16;
@@ -128,6 +128,8 @@ void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, 
 void launch_write_header(const ghf_code* d_code, uint8_t* d_out, uint64_t cap, int* d_status, hipStream_t s);
 void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, const uint32_t* d_chunk_hist,
                  const ghf_code* d_code, uint64_t* d_chunk_off, uint64_t* d_total_bits, hipStream_t s);
+// in-place exclusive scan of d_v[0..count), d_v[count] = total, *d_total = total (one workgroup)
+void launch_scan(uint64_t* d_v, uint32_t count, uint64_t* d_total, hipStream_t s);
 void launch_emit(const EmitParams& p, hipStream_t s);
 void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_status, hipStream_t s);
 void launch_decode(const DecParams& p, hipStream_t s);

@@ -55,15 +55,16 @@ typedef struct ghf_code {
  * the two arrays are device memory (ghf_index_alloc). */
 typedef struct ghf_index {
   uint64_t n_symbols;     /* input bytes covered */
-  uint32_t chunk_symbols; /* symbols per chunk (power of two) */
+  uint32_t chunk_symbols; /* symbols per index block (4096 = 64 segments) */
   uint32_t seg_symbols;   /* symbols per segment (64) */
-  uint64_t n_chunks;
+  uint64_t n_chunks;      /* index blocks */
   uint64_t n_segs;
   uint32_t flags;    /* GHF_INDEX_NO_END_MARK: the buffer is a shard that was emitted without GHF_EMIT_LAST */
   uint32_t reserved;
-  uint64_t* d_chunk_bit; /* [n_chunks] bit offset of each chunk's first code, counted from byte 0 of the d_out the
+  uint64_t* d_chunk_bit; /* [n_chunks] bit offset of each block's first code, counted from byte 0 of the d_out the
                             emit call wrote into (= absolute stream bit, header included, unless GHF_EMIT_REBASE) */
-  uint32_t* d_seg_bit;   /* [n_segs]   bit offset of each segment relative to its chunk's first code */
+  uint32_t* d_seg_bit;   /* [n_segs]   bit offset of each segment's END relative to its block's first code (a segment
+                            starts where its predecessor in the block ends; the first one at the block's first code) */
 } ghf_index;
 
 #define GHF_INDEX_NO_END_MARK 1u
