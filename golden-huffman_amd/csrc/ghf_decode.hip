@@ -173,9 +173,18 @@ constexpr int kDec7LutSlots = 1 << kDec7LutLog2;
 constexpr int kDec7SmallSlots = 1024;  // pair mode (max_len <= 5): the one-symbol table for ragged tails and the end mark, 32 copies
 constexpr int kDec7InBytes = 4608;  // staged span per wave: 4096 symbols at <= 9 bits average (a byte-Huffman code averages <= 8.1)
 constexpr int kDec7InWords = kDec7InBytes / 4;
+// The input tiles are PADDED: 16 bytes after every 128.  A lane's segment of uniform bytes is ~64 bytes long, so the 32
+// lanes of an LDS group read "their current word" 16 words apart -- two banks for 32 lanes, a 16-way conflict on every
+// window refill (PMC, round 2: 68 % of this kernel's LDS cycles).  With the pad, lanes two apart shift by four banks and
+// only lanes l, l + 16 still share one (2-way: free).  All tiles live in one logical byte space (tile stride a multiple
+// of 128) so that logical -> physical is two VALU instructions, no per-wave base: phys = la + (la >> 7 << 4).
+constexpr int kDec7TileLog = kDec7InBytes + 128;                  // logical bytes per wave (16 zero bytes + slack behind the span)
+constexpr int kDec7TilePhys = kDec7TileLog / 128 * 144;           // 5328
+static_assert(kDec7TileLog % 128 == 0 && kDec7TilePhys >= 4096 + 16, "tile doubles as the 4 KiB transposition buffer");
+__device__ __forceinline__ uint32_t in_phys(uint32_t la) { return la + ((la >> 7) << 4); }
 constexpr uint32_t kEntEnd = 1u << 16, kEntNone = 1u << 17;
 struct DecLds7 {
-  alignas(16) uint32_t in[kDec7Waves][kDec7InWords + 4];  // compressed span of the wave's group, big-endian words; then its output
+  alignas(128) uint8_t in[kDec7Waves * kDec7TilePhys];  // compressed spans of the waves' groups, big-endian words, padded; then their output
   alignas(16) uint32_t lut[kDec7LutSlots + kDec7SmallSlots];
   uint32_t fcl[36];
   uint32_t sp[36];
@@ -252,13 +261,17 @@ __device__ __forceinline__ uint32_t dec_long(const LT& L, uint32_t hi, int lut_b
   return (k < GHF_NSYM ? (uint32_t)L.symbol[k] : 256u) | ((uint32_t)l << 16);
 }
 
+// big-endian word at logical byte address la of the padded input tiles
+__device__ __forceinline__ uint32_t in_word(const uint8_t* lin, uint32_t la) { return *reinterpret_cast<const uint32_t*>(lin + in_phys(la)); }
+
 template <bool STAGED>
 struct DecIn {
-  const uint32_t* in;   // staged big-endian words
+  const uint8_t* lin;   // staged: L.in
+  uint32_t la0;         // staged: logical byte address of the wave's tile
   const uint8_t* src;   // unstaged: raw bytes of the span
   uint64_t span;
   __device__ __forceinline__ uint32_t fetch(uint32_t widx) const {
-    if (STAGED) return in[widx];
+    if (STAGED) return in_word(lin, la0 + 4u * widx);
     const uint64_t b = (uint64_t)widx * 4;
     uint32_t r = 0;
     for (int k = 0; k < 4; ++k) r = (r << 8) | (b + k < span ? (uint32_t)src[b + k] : 0u);
@@ -284,24 +297,28 @@ __device__ __forceinline__ uint32_t dec_long_entry(const LT& L, uint32_t v, int 
 // The window W holds 64 stream bits, `o` of them (from the top) already consumed; one symbol costs a 64-bit shift, the
 // table lookup and an add.  K symbols are decoded between two refill checks -- K * max_len <= 33 keeps o + max_len <= 64
 // at every lookup.
-#define GHF_REFILL()       \
-  if (o >= 32u) {          \
-    W = (W << 32) | nextw; \
-    o -= 32u;              \
-    nextw = *wp++;         \
+#define GHF_REFILL()           \
+  if (o >= 32u) {              \
+    W = (W << 32) | nextw;     \
+    o -= 32u;                  \
+    nextw = in_word(lin, la);  \
+    la += 4u;                  \
   }
+#define GHF_WINDOW_OPEN()                                              \
+  uint32_t la = la0 + ((pos >> 5) << 2);                               \
+  const uint32_t la_first = la;                                        \
+  uint32_t o = pos & 31u;                                              \
+  const uint32_t o0 = o;                                               \
+  uint64_t W = ((uint64_t)in_word(lin, la) << 32) | in_word(lin, la + 4u); \
+  uint32_t nextw = in_word(lin, la + 8u);                              \
+  la += 12u
+#define GHF_WINDOW_USED() ((la - la_first - 12u) * 8u + o - o0)
 
 // HOT: the 64 symbols of a full, staged segment whose codes all fit the direct table.  Straight-line code; the 64 bytes
 // stay in registers.  Returns the OR of all entries (kEntEnd / kEntNone set: not 64 data symbols -> corrupt).
 template <int K>
-__device__ __forceinline__ uint32_t dec_hot(const uint32_t* in, const DecLut& T, uint32_t pos, uint32_t (&out)[16], uint32_t& used) {
-  const uint32_t* wp = in + (pos >> 5);
-  const uint32_t* const wp0 = wp;
-  uint32_t o = pos & 31u;
-  const uint32_t o0 = o;
-  uint64_t W = ((uint64_t)wp[0] << 32) | wp[1];
-  uint32_t nextw = wp[2];
-  wp += 3;
+__device__ __forceinline__ uint32_t dec_hot(const uint8_t* lin, uint32_t la0, const DecLut& T, uint32_t pos, uint32_t (&out)[16], uint32_t& used) {
+  GHF_WINDOW_OPEN();
   uint32_t acc = 0;
 #pragma unroll
   for (int d = 0; d < 16; ++d) {
@@ -319,21 +336,15 @@ __device__ __forceinline__ uint32_t dec_hot(const uint32_t* in, const DecLut& T,
     const uint32_t hi = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0400u);
     out[d] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
   }
-  used = (uint32_t)(wp - wp0 - 3) * 32u + o - o0;
+  used = GHF_WINDOW_USED();
   return acc;
 }
 
 // HOT, small alphabet (2 * max_len <= 10): any two codes fit lut2's index, so one lookup yields two symbols and the serial
 // shift -> lookup -> add chain is half as long.  Three lookups (<= 30 bits) per refill check.
 // entry = sym0 | sym1 << 8 | (len0 + len1) << 16 | bit 30: not two data symbols
-__device__ __forceinline__ uint32_t dec_hot_pair(const uint32_t* in, const DecLut& T2, uint32_t pos, uint32_t (&out)[16], uint32_t& used) {
-  const uint32_t* wp = in + (pos >> 5);
-  const uint32_t* const wp0 = wp;
-  uint32_t o = pos & 31u;
-  const uint32_t o0 = o;
-  uint64_t W = ((uint64_t)wp[0] << 32) | wp[1];
-  uint32_t nextw = wp[2];
-  wp += 3;
+__device__ __forceinline__ uint32_t dec_hot_pair(const uint8_t* lin, uint32_t la0, const DecLut& T2, uint32_t pos, uint32_t (&out)[16], uint32_t& used) {
+  GHF_WINDOW_OPEN();
   uint32_t acc = 0;
 #pragma unroll
   for (int d = 0; d < 16; ++d) {
@@ -348,22 +359,16 @@ __device__ __forceinline__ uint32_t dec_hot_pair(const uint32_t* in, const DecLu
     acc |= e[0] | e[1];
     out[d] = __builtin_amdgcn_perm(e[1], e[0], 0x05040100u);  // {a.sym0, a.sym1, b.sym0, b.sym1}
   }
-  used = (uint32_t)(wp - wp0 - 3) * 32u + o - o0;
+  used = GHF_WINDOW_USED();
   return acc;
 }
 
 // HOT for codes beyond the direct table (max_len > 12; no BASELINE config): the reference's linear extension on a miss,
 // four output bytes per store, straight to HBM.
 template <int K>
-__device__ __forceinline__ uint32_t dec_hot_long(const DecLds7& L, const uint32_t* in, const DecLut& T, int lut_bits, int max_len,
+__device__ __forceinline__ uint32_t dec_hot_long(const DecLds7& L, const uint8_t* lin, uint32_t la0, const DecLut& T, int lut_bits, int max_len,
                                                  uint32_t pos, uint8_t* optr, uint32_t& used) {
-  const uint32_t* wp = in + (pos >> 5);
-  const uint32_t* const wp0 = wp;
-  uint32_t o = pos & 31u;
-  const uint32_t o0 = o;
-  uint64_t W = ((uint64_t)wp[0] << 32) | wp[1];
-  uint32_t nextw = wp[2];
-  wp += 3;
+  GHF_WINDOW_OPEN();
   uint32_t acc = 0;
 #pragma unroll 1
   for (int d = 0; d < 16; ++d) {
@@ -380,10 +385,12 @@ __device__ __forceinline__ uint32_t dec_hot_long(const DecLds7& L, const uint32_
     }
     reinterpret_cast<uint32_t*>(optr)[d] = w;
   }
-  used = (uint32_t)(wp - wp0 - 3) * 32u + o - o0;
+  used = GHF_WINDOW_USED();
   return acc;
 }
 #undef GHF_REFILL
+#undef GHF_WINDOW_OPEN
+#undef GHF_WINDOW_USED
 
 // COLD: whatever the hot passes do not take -- the stream's last group (ragged, followed by the end mark), spans that do
 // not fit the LDS tile (read from memory), unaligned output.  One symbol at a time, one byte per store.
@@ -516,7 +523,9 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
   const uint64_t ngroups = (P.n_segs + 63) >> 6;
   const uint64_t full_bytes = P.stream_bytes & ~15ull;  // whole 16-byte vectors of the stream
   const bool out_aligned = (((uintptr_t)P.out) & 15u) == 0;
-  uint32_t* in = L.in[wave];
+  const uint8_t* const lin = L.in;
+  const uint32_t la0 = (uint32_t)wave * kDec7TileLog;             // this wave's tile in the logical (unpadded) byte space
+  uint32_t* const tile = reinterpret_cast<uint32_t*>(L.in + (uint32_t)wave * kDec7TilePhys);  // ... and as plain memory (copy-out)
   uint32_t bad_acc = 0;
   // groups are handed out by a global ticket counter, not by a fixed stride: a wave that starts late (e.g. because
   // another kernel occupied its CU) simply takes fewer groups instead of becoming the kernel's straggler
@@ -540,17 +549,25 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
   const uint64_t glast = ngroups - 1;
   auto clampg = [&](uint64_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
 
-  // issue the 16-byte loads of a group's span (vector k of this lane = bytes byte0 + k*1024 + lane*16 ..)
+  // vector k of a lane = bytes byte0 + k*1024 + lane*16 .. of the stream; it is loaded when it begins inside the span
+  // and ends inside the stream's whole 16-byte vectors
+  auto vec_lim = [&](const DecGroup& G) -> uint32_t {  // wave-uniform: o + 16 <= lim  <=>  o < span && byte0 + o + 16 <= full_bytes
+    if (G.byte0 > full_bytes) return 0u;
+    const uint64_t room = full_bytes - G.byte0;
+    const uint64_t a = (uint64_t)G.span + 15u;
+    return (uint32_t)(a < room ? a : (room > 0x7FFFFFFFull ? 0x7FFFFFFFull : room));
+  };
   auto vec_ok = [&](const DecGroup& G, int k, int lane) -> bool {
-    const uint32_t o = (uint32_t)k * 1024u + (uint32_t)lane * 16u;
-    const uint64_t room = full_bytes - G.byte0;  // byte0 <= full_bytes whenever span > 0 matters; else no lane is ok
-    return o < G.span && G.byte0 <= full_bytes && (uint64_t)o + 16 <= room;
+    return (uint32_t)k * 1024u + (uint32_t)lane * 16u + 16u <= vec_lim(G);
   };
   auto issue = [&](const DecGroup& G, uint4 (&R)[kDecVec], int lane) {
-    const uint8_t* base = P.stream + G.byte0 + (uint32_t)lane * 16u;
+    const uint32_t lim = vec_lim(G);
+    const uint8_t* base = P.stream + (lim ? G.byte0 : 0ull);  // uniform
 #pragma unroll
-    for (int k = 0; k < kDecVec; ++k)  // lanes behind the span re-read byte 0 (an L2 hit)
-      R[k] = *reinterpret_cast<const uint4*>(vec_ok(G, k, lane) ? base + k * 1024 : P.stream);
+    for (int k = 0; k < kDecVec; ++k) {  // lanes behind the span re-read the span's first bytes (an L2 hit)
+      const uint32_t o = (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+      R[k] = *reinterpret_cast<const uint4*>(base + (o + 16u <= lim ? o : 0u));
+    }
   };
 
   // one instantiation of the whole loop per decoder variant: the hot pass then holds ONE straight-line decoder
@@ -574,23 +591,26 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
       // recomputed per pass with a few VALU instructions instead of being hoisted out of the loop and then spilled
       int ln = lane;
       asm volatile("" : "+v"(ln));
-      // ---- 1. this group's span: registers -> LDS (big-endian words); everything behind it reads as zero
+      // ---- 1. this group's span: registers -> LDS (big-endian words).  HOT: whatever a lane loaded behind the span is
+      // harmless (only a corrupt stream reads it, and that is caught by the segment-end check); else it reads as zero
       wave_sync();
-  #pragma unroll
+#pragma unroll
       for (int k = 0; k < kDecVec; ++k) {
         const uint32_t o = (uint32_t)k * 1024u + (uint32_t)ln * 16u;
         uint4 v = R[k];
-        v = vec_ok(cur, k, ln) ? make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)) : make_uint4(0, 0, 0, 0);
-        if ((k + 1) * 1024 <= kDec7InBytes || o < (uint32_t)kDec7InBytes) *reinterpret_cast<uint4*>(in + (o >> 2)) = v;
+        v = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+        if (!HOT && !vec_ok(cur, k, ln)) v = make_uint4(0, 0, 0, 0);
+        if ((k + 1) * 1024 <= kDec7InBytes || o < (uint32_t)kDec7InBytes)
+          *reinterpret_cast<uint4*>(L.in + in_phys(la0 + o)) = v;
       }
-      if (ln < 4) in[kDec7InWords + ln] = 0;
+      if (ln < 4) *reinterpret_cast<uint32_t*>(L.in + in_phys(la0 + kDec7InBytes + 4u * ln)) = 0;
       if (!HOT && cur.byte0 + cur.span > full_bytes && full_bytes >= cur.byte0 && ln == 0) {
         // the stream's last, incomplete 16 bytes: byte loads, never past the end of the buffer
         uint32_t q[4] = {0, 0, 0, 0};
         for (uint64_t j = 0; full_bytes + j < P.stream_bytes; ++j) q[j >> 2] |= (uint32_t)P.stream[full_bytes + j] << (24 - 8 * (j & 3));
         const uint64_t w = (full_bytes - cur.byte0) >> 2;
         if (w + 3 < (uint64_t)kDec7InWords + 4) {
-          in[w] = q[0]; in[w + 1] = q[1]; in[w + 2] = q[2]; in[w + 3] = q[3];
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t*>(L.in + in_phys(la0 + 4u * (uint32_t)(w + j))) = q[j];
         }
       }
       wave_sync();
@@ -608,10 +628,10 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
         if (VAR <= 3) {
           uint32_t out[16];
           // K = 33 / max_len symbols per refill check
-          if (VAR == 0) acc = dec_hot_pair(in, T2, cur.pos, out, used) >> 14;  // bit 30 -> bit 16
-          else if (VAR == 1) acc = dec_hot<4>(in, T1, cur.pos, out, used);
-          else if (VAR == 2) acc = dec_hot<3>(in, T1, cur.pos, out, used);
-          else acc = dec_hot<2>(in, T1, cur.pos, out, used);
+          if (VAR == 0) acc = dec_hot_pair(lin, la0, T2, cur.pos, out, used) >> 14;  // bit 30 -> bit 16
+          else if (VAR == 1) acc = dec_hot<4>(lin, la0, T1, cur.pos, out, used);
+          else if (VAR == 2) acc = dec_hot<3>(lin, la0, T1, cur.pos, out, used);
+          else acc = dec_hot<2>(lin, la0, T1, cur.pos, out, used);
           // ---- 3. copy-out through the input tile (dead now): ln-major 64-byte rows, pieces XOR-swizzled so that the 16
           // lanes of a write phase hit 16 different bank groups; then four fully coalesced 1 KiB stores per wave,
           // straight-line, so that the compiler can count them
@@ -619,19 +639,19 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
           const uint32_t osw = ((uint32_t)ln >> 2) & 3u;
   #pragma unroll
           for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<uint4*>(in + ln * 16 + (((uint32_t)q ^ osw) << 2)) = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+            *reinterpret_cast<uint4*>(tile + ln * 16 + (((uint32_t)q ^ osw) << 2)) = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
           wave_sync();
           uint8_t* og = P.out + seg0 * kSegSymbols + (uint32_t)ln * 16;
   #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const uint32_t sl = (uint32_t)r * 16 + ((uint32_t)ln >> 2);  // the ln whose row holds my piece
             const uint32_t piece = ((uint32_t)ln & 3u) ^ ((sl >> 2) & 3u);
-            *reinterpret_cast<uint4*>(og + r * 1024) = *reinterpret_cast<const uint4*>(in + sl * 16 + piece * 4);
+            *reinterpret_cast<uint4*>(og + r * 1024) = *reinterpret_cast<const uint4*>(tile + sl * 16 + piece * 4);
           }
         } else if (VAR == 4) {
-          acc = dec_hot_long<2>(L, in, T1, lut_bits, max_len, cur.pos, P.out + sym0, used);
+          acc = dec_hot_long<2>(L, lin, la0, T1, lut_bits, max_len, cur.pos, P.out + sym0, used);
         } else {
-          acc = dec_hot_long<1>(L, in, T1, lut_bits, max_len, cur.pos, P.out + sym0, used);
+          acc = dec_hot_long<1>(L, lin, la0, T1, lut_bits, max_len, cur.pos, P.out + sym0, used);
         }
         if (used != cur.expect) acc |= kEntNone;
         bad_acc |= acc;
@@ -647,10 +667,10 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
           const int has_next = seg + 1 < P.n_segs ? 1 : (P.no_end_mark ? 2 : 0);
           const uint8_t* src = P.stream + cur.byte0;
           if (staged) {
-            DecIn<true> I{in, src, cur.span};
+            DecIn<true> I{lin, la0, src, cur.span};
             bad_acc |= dec_cold<true>(L, I, T1, lut_bits, max_len, cur.pos, cnt, valid, P.out + sym0, has_next, cur.expect);
           } else {
-            DecIn<false> I{in, src, cur.span};
+            DecIn<false> I{lin, la0, src, cur.span};
             bad_acc |= dec_cold<false>(L, I, T1, lut_bits, max_len, cur.pos, cnt, valid, P.out + sym0, has_next, cur.expect);
           }
         }

@@ -160,7 +160,7 @@ def test_emit_kernel_has_no_scratch():
 
 
 def test_decode_kernel_scratch_reloads_are_followed_by_full_waits():
-    text = _kernel_asm("ghf_kernels")
+    text = _kernel_asm("ghf_decode")
     # K7 may spill (its 128-VGPR budget is tight), but only where it does no harm: every scratch reload must be
     # followed by a FULL vector-memory wait before any counted one (so nothing is ever inferred from the order in
     # which a scratch reload and a global load retire)
