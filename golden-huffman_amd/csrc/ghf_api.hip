@@ -24,7 +24,7 @@ struct ghf_ctx {
   size_t chunk_off_cap = 0;  // in entries
   const uint8_t* hist_in = nullptr;  // what d_chunk_hist currently describes
   uint64_t hist_n = 0;
-  uint32_t hist_chunk_log2 = 0;
+  uint32_t hist_chunk = 0;
   const uint8_t* plan_in = nullptr;  // what d_chunk_off currently describes
   uint64_t plan_n = 0;
   const ghf_code* plan_code = nullptr;
@@ -257,7 +257,7 @@ int ghf_memset_d(ghf_ctx* c, void* d_dst, int value, size_t bytes) {
 }
 
 // ---------------------------------------------------------------------------------------------- encode
-uint32_t ghf_chunk_symbols(size_t n) { return 1u << chunk_log2_for(n); }
+uint32_t ghf_chunk_symbols(size_t n) { return chunk_symbols_for(n); }
 size_t ghf_header_bytes(int max_len) { return 1040 + 8 * (size_t)max_len; }
 
 size_t ghf_compress_bound(size_t n) {
@@ -271,15 +271,15 @@ size_t ghf_compress_bound(size_t n) {
 int ghf_histogram(ghf_ctx* c, const uint8_t* d_in, size_t n, uint64_t* d_hist) {
   if (!c || !d_hist || (n && !d_in)) return GHF_E_INVAL;
   GHF_HIP(c, hipSetDevice(c->device));
-  const uint32_t cl = chunk_log2_for(n);
-  const size_t nchunks = (n + ((size_t)1 << cl) - 1) >> cl;
+  const uint32_t cl = chunk_symbols_for(n);
+  const size_t nchunks = (size_t)chunk_count_for(n);
   int rc = ensure_ws(c, nchunks);
   if (rc) return rc;
   launch_histogram(d_in, n, cl, (uint32_t)nchunks, c->d_chunk_hist, d_hist, c->d_hist_acc, c->stream);
   GHF_HIP(c, hipGetLastError());
   c->hist_in = d_in;
   c->hist_n = n;
-  c->hist_chunk_log2 = cl;
+  c->hist_chunk = cl;
   return GHF_OK;
 }
 
@@ -306,11 +306,11 @@ int ghf_write_header(ghf_ctx* c, const ghf_code* d_code, uint8_t* d_out, size_t 
 int ghf_encode_plan(ghf_ctx* c, const uint8_t* d_in, size_t n, const ghf_code* d_code, uint64_t* d_total_bits) {
   if (!c || !d_code || (n && !d_in)) return GHF_E_INVAL;
   GHF_HIP(c, hipSetDevice(c->device));
-  const uint32_t cl = chunk_log2_for(n);
-  const size_t nchunks = (n + ((size_t)1 << cl) - 1) >> cl;
+  const uint32_t cl = chunk_symbols_for(n);
+  const size_t nchunks = (size_t)chunk_count_for(n);
   int rc = ensure_ws(c, nchunks);
   if (rc) return rc;
-  const bool have_hist = c->hist_in == d_in && c->hist_n == n && c->hist_chunk_log2 == cl && n != 0;
+  const bool have_hist = c->hist_in == d_in && c->hist_n == n && c->hist_chunk == cl && n != 0;
   launch_plan(d_in, n, cl, (uint32_t)nchunks, have_hist ? c->d_chunk_hist : nullptr, d_code, c->d_chunk_off,
               d_total_bits ? d_total_bits : c->d_u64, c->stream);
   GHF_HIP(c, hipGetLastError());
@@ -329,8 +329,8 @@ int ghf_encode_emit(ghf_ctx* c, const uint8_t* d_in, size_t n, const ghf_code* d
   if (c->plan_in != d_in || c->plan_n != n || c->plan_code != d_code)
     return fail(c, GHF_E_INVAL, "ghf_encode_emit: call ghf_encode_plan on the same (d_in, n, d_code) first");
   GHF_HIP(c, hipSetDevice(c->device));
-  const uint32_t cl = chunk_log2_for(n);
-  const size_t nchunks = (n + ((size_t)1 << cl) - 1) >> cl;
+  const uint32_t cl = chunk_symbols_for(n);
+  const size_t nchunks = (size_t)chunk_count_for(n);
   if (index) {
     if (index->n_symbols != n || index->chunk_symbols != (uint32_t)kBlockSymbols || index->seg_symbols != (uint32_t)kSegSymbols ||
         !index->d_chunk_bit || !index->d_seg_bit)
@@ -344,7 +344,7 @@ int ghf_encode_emit(ghf_ctx* c, const uint8_t* d_in, size_t n, const ghf_code* d
   p.d_start_bit = d_start_bit;
   p.out = d_out;
   p.cap = cap;
-  p.chunk_log2 = cl;
+  p.chunk = cl;
   p.nchunks = (uint32_t)nchunks;
   p.chunk_bit = index ? index->d_chunk_bit : nullptr;
   p.seg_bit = index ? index->d_seg_bit : nullptr;

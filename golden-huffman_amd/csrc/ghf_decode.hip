@@ -501,8 +501,6 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
   __syncthreads();
   if (L.status0 != 0) return;
   const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
-  dec_lds_load7(L, P.dt, tid, kDec7Threads);
-  __syncthreads();
   const int pair_bits = P.dt->pair_bits;
   const int lane = tid & 63;
   // this lane's replicas: T1 = one symbol per lookup, T2 = two (small alphabets only)
@@ -544,7 +542,6 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
     return 3 * nwaves + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * ncls + cls;
   };
   uint64_t group = wid;
-  if (group >= ngroups) return;
   uint64_t g1 = wid + nwaves, g2 = wid + 2 * nwaves;  // this wave's next two groups
   const uint64_t glast = ngroups - 1;
   auto clampg = [&](uint64_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
@@ -570,12 +567,20 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
     }
   };
 
+  // The first group's side-car words are requested BEFORE the table is built: one of the two dependent memory round trips
+  // in front of the first decode then hides behind the ~3 us of table replication.  (The span loads do not: 20 more
+  // registers alive across six loop nests made the allocator spill in all of them.)
+  DecMeta M;  // raw side-car words of the group after `cur` (of the one after that once the pass has issued its loads)
+  const bool mine = group < ngroups;
+  if (mine) dec_issue_meta(P, group, lane, M);
+  dec_lds_load7(L, P.dt, tid, kDec7Threads);
+  __syncthreads();
+  if (!mine) return;
+
   // one instantiation of the whole loop per decoder variant: the hot pass then holds ONE straight-line decoder
   auto run = [&](auto var_tag) {
     DecGroup cur, nxt;
     uint4 R[kDecVec];
-    DecMeta M;  // raw side-car words of the group after `cur` (of the one after that once the pass has issued its loads)
-    dec_issue_meta(P, group, lane, M);
     dec_group(P, group, lane, max_len, M, cur);
     issue(cur, R, lane);
     dec_issue_meta(P, clampg(g1), lane, M);

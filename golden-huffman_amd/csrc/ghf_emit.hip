@@ -196,12 +196,32 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
                                            uint32_t* flat, uint32_t* st, int lane) {
   typedef EmitMode<WIDE> M;
   constexpr int NI = M::NI;
-  const uint64_t chunk = 1ull << P.chunk_log2;
-  const uint64_t sym0 = (uint64_t)c << P.chunk_log2;
+  const uint64_t chunk = P.chunk;
+  const uint64_t sym0 = (uint64_t)c * chunk;
   const uint64_t nsym = (P.n - sym0 < chunk) ? (P.n - sym0) : chunk;
   const uint8_t* pin = P.in + sym0;
   const bool aligned = (((uintptr_t)pin) & 15u) == 0;
-  const uint64_t Pc = G.start_bit + P.chunk_off[c];
+  // ---- everything this chunk's start needs from memory is requested at once, oldest first: the chunk's bit offset, the
+  // two symbols per lane in front of it, its first two tiles (three dependent round trips otherwise, per chunk)
+  const uint64_t chunk_off = P.chunk_off[c];
+  uint32_t prev0 = 0, prev1 = 0;
+  if (c > 0) {
+    // the previous chunk's last 128 symbols (it is a full chunk, >= 4096 symbols), two per lane: a code has at least
+    // one bit, so they cover the <= 127 bits in front of this chunk that share its first unit
+    const uint8_t* pp = pin - 128 + 2 * lane;
+    prev0 = pp[0];
+    prev1 = pp[1];
+  }
+  const uint64_t nfull = aligned ? (nsym / kSymPerIter) : 0;
+  const uint4* pv = reinterpret_cast<const uint4*>(pin) + lane;
+  const bool streamed = !WIDE && nfull >= 2;  // (codes beyond 16 bits take the plain loop below: rare, and it keeps that
+                                              // instantiation free of spills)
+  uint4 A = make_uint4(0, 0, 0, 0), B = A;
+  if (streamed) {
+    A = pv[0];
+    B = pv[64];
+  }
+  const uint64_t Pc = G.start_bit + chunk_off;
   WaveOut W;
   W.flat = flat;
   W.st = st;
@@ -215,12 +235,9 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
   // ---- the bits in front of this chunk's first code that share its first 16-byte unit
   if (W.carry) {
     if (c > 0) {
-      // the previous chunk's last 128 symbols (it is a full chunk, >= 4096 symbols), two per lane: a code has at least
-      // one bit, so they cover the <= 127 bits wanted
-      const uint8_t* pp = pin - 128 + 2 * lane;
       uint32_t c0, l0, c1, l1;
-      M::one(tab, lane, pp[0], c0, l0);
-      M::one(tab, lane, pp[1], c1, l1);
+      M::one(tab, lane, prev0, c0, l0);
+      M::one(tab, lane, prev1, c1, l1);
       uint64_t pr = ((uint64_t)c0 << l1) | c1;
       uint32_t lp = l0 + l1;
       const uint32_t incl = wave_incl_scan_u32(lp);
@@ -270,16 +287,12 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
   auto block_dst = [&](uint64_t it) -> uint64_t* {  // stored with the tile's units (after its drain)
     return (blockp && (it & 3) == 0 && lane == 0) ? blockp + (it >> 2) : nullptr;
   };
-  const uint64_t nfull = aligned ? (nsym / kSymPerIter) : 0;
-  const uint4* pv = reinterpret_cast<const uint4*>(pin) + lane;
   uint32_t* const segp = P.seg_bit ? P.seg_bit + ((sym0 + (uint64_t)lane * 16) >> 6) : nullptr;
   uint64_t it = 0;
   // ---- full 1 KiB tiles, two per trip.  While tile `it` is packed, the loads of tiles it+1 and it+2 are in flight;
   //      A and B are each re-loaded right after they were consumed, so no register ever has to be copied while
   //      its load is pending (the last prefetches are clamped to the last full tile and simply unused).
-  //      (Codes beyond 16 bits take the plain loop below: rare, and it keeps that instantiation free of spills.)
-  if (!WIDE && nfull >= 2) {
-    uint4 A = pv[0], B = pv[64];
+  if (streamed) {
     __builtin_amdgcn_s_waitcnt(0x0F71);  // vmcnt(1): A has arrived, so the loop is entered in the state its back edge leaves
     for (; it + 1 < nfull; it += 2) {
       {

@@ -13,9 +13,13 @@ constexpr int kSymPerLane = 16;         // one 16-byte vector load = one lane's 
 constexpr int kSymPerIter = kWave * kSymPerLane;  // 1 KiB of input per wave iteration
 constexpr int kSegSymbols = 64;         // side-car granularity (4 lanes of K5, one lane of K7)
 constexpr int kBlockSymbols = 4096;     // side-car block = 64 segments = one K7 group = 4 K5 tiles; absolute bit per block
-constexpr uint32_t kMinChunkLog2 = 12;  // 4 KiB
-constexpr uint32_t kMaxChunkLog2 = 20;  // 1 MiB
-constexpr uint32_t kTargetChunks = 8192;
+// A chunk = the input one K5 wave packs (and the unit K1 prices for K4).  Chunks are sized so that ALL of them are resident
+// at once: K5 keeps 3 workgroups x 8 waves on each of the 256 CUs, and a grid of 1.33 rounds (8192 power-of-two chunks, as in
+// round 1) spends its last third with a third of the waves -- too few loads in flight to keep HBM busy.  Multiples of
+// 16 KiB (four rounds of K1's 4 KiB vector rows), at most 1 MiB.
+constexpr uint32_t kChunkQuantum = 16384;
+constexpr uint32_t kMaxChunk = 1u << 20;
+constexpr uint32_t kEmitSlots = 256 * 3 * 8;
 
 // K1 histogram
 constexpr int kHistThreads = 256;
@@ -35,10 +39,16 @@ constexpr int kDecLutBitsMax = 12;
 constexpr int kDecInBytes = 5120;                 // staged compressed span per wave (4096 symbols at <= 10 bits average)
 constexpr int kDecInWords = kDecInBytes / 4;
 
-inline uint32_t chunk_log2_for(uint64_t n) {
-  uint32_t l = kMinChunkLog2;
-  while (l < kMaxChunkLog2 && ((n + ((1ull << l) - 1)) >> l) > kTargetChunks) ++l;
-  return l;
+inline uint32_t chunk_symbols_for(uint64_t n) {
+  const uint64_t per_slot = (n + kEmitSlots - 1) / kEmitSlots;
+  uint64_t c = (per_slot + kChunkQuantum - 1) / kChunkQuantum * kChunkQuantum;
+  if (c < kChunkQuantum) c = kChunkQuantum;
+  if (c > kMaxChunk) c = kMaxChunk;
+  return (uint32_t)c;
+}
+inline uint64_t chunk_count_for(uint64_t n) {
+  const uint64_t c = chunk_symbols_for(n);
+  return (n + c - 1) / c;
 }
 
 // decode-side tables derived from ghf_code (built on the device by k_build_decode_tables)
@@ -71,7 +81,7 @@ struct EmitParams {
   const uint64_t* d_start_bit;
   uint8_t* out;
   uint64_t cap;
-  uint32_t chunk_log2;
+  uint32_t chunk;       // symbols per chunk (a multiple of 16 KiB)
   uint32_t nchunks;
   uint64_t* chunk_bit;  // side-car (may be null): [n / 4096] absolute start bit of every block
   uint32_t* seg_bit;    // side-car (may be null): [n / 64] end bit of every segment, relative to its block
@@ -122,11 +132,11 @@ void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_symb
 // K1 scratch, all zero between launches: 32 replicas of the 256 totals, the arrival counter (word 8192), 16 ticket
 // counters (word 8208 + 16 k, one 128-byte line each)
 constexpr size_t kHistAccWords = 32 * 256 + 16 + 16 * 16;
-void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, uint32_t* d_chunk_hist,
+void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk, uint32_t nchunks, uint32_t* d_chunk_hist,
                       uint64_t* d_hist, uint64_t* d_acc, hipStream_t s);
 void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, uint32_t flags, hipStream_t s);
 void launch_write_header(const ghf_code* d_code, uint8_t* d_out, uint64_t cap, int* d_status, hipStream_t s);
-void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, const uint32_t* d_chunk_hist,
+void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk, uint32_t nchunks, const uint32_t* d_chunk_hist,
                  const ghf_code* d_code, uint64_t* d_chunk_off, uint64_t* d_total_bits, hipStream_t s);
 // in-place exclusive scan of d_v[0..count), d_v[count] = total, *d_total = total (one workgroup)
 void launch_scan(uint64_t* d_v, uint32_t count, uint64_t* d_total, hipStream_t s);

@@ -31,7 +31,7 @@ __device__ __forceinline__ void hist_vec(uint32_t* lh, uint32_t rep, const uint4
 }
 
 __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __restrict__ in, uint64_t n,
-                                                            uint32_t chunk_log2, uint32_t nchunks,
+                                                            uint32_t chunk32, uint32_t nchunks,
                                                             uint32_t* __restrict__ chunk_hist,
                                                             unsigned long long* __restrict__ hist,
                                                             unsigned long long* __restrict__ acc /* [32][256] + done */) {
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
   __syncthreads();
   uint32_t prev = 0;
   unsigned long long total = 0;
-  const uint64_t chunk = 1ull << chunk_log2;
+  const uint64_t chunk = chunk32;
 
   __shared__ uint32_t s_tick;
   // end of a chunk: thread t sums the 32 replicas of bin t (rotated start: 32 lanes on 32 banks); the counters
@@ -69,9 +69,9 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
   // keeps a late or slow workgroup from becoming the kernel's straggler.  Per thread the vectors of consecutive
   // chunks form ONE stream: four 16-byte loads are always in flight (A/B and C/D alternate, no register copies),
   // also across the chunk boundary -- the next chunk's first vectors are requested while this one is reduced.
-  const uint32_t vlog = chunk_log2 - 12;  // vectors per thread per chunk = 2^vlog (256 threads x 16 B = 4 KiB)
-  const uint32_t nfullchunks = (uint32_t)(n >> chunk_log2);
-  const bool fast = vlog >= 2 && (((uintptr_t)in) & 15u) == 0 && nfullchunks > 0;
+  const uint32_t V = chunk32 >> 12;  // vectors per thread per chunk (256 threads x 16 B = 4 KiB), a multiple of 4
+  const uint32_t nfullchunks = (uint32_t)(n / chunk);
+  const bool fast = (V & 3u) == 0 && V != 0 && (((uintptr_t)in) & 15u) == 0 && nfullchunks > 0;
   if (fast) {
     const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;
     const uint32_t cls = blockIdx.x % ncls;
@@ -81,10 +81,9 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
     auto draw = [&]() -> uint32_t { return 2u * gridDim.x + (uint32_t)atomicAdd(tick, 1ull) * ncls + cls; };  // thread 0 only
     uint32_t cur = blockIdx.x;
     uint32_t nxt = blockIdx.x + gridDim.x;
-    const uint32_t V = 1u << vlog;
     auto vptr = [&](uint32_t c, uint32_t j) -> const uint4* {
       if (c >= nfullchunks) c = nfullchunks - 1;  // past the end: redundant, harmless loads
-      return reinterpret_cast<const uint4*>(in + ((uint64_t)c << chunk_log2)) + (uint64_t)j * kHistThreads + tid;
+      return reinterpret_cast<const uint4*>(in + (uint64_t)c * chunk) + (uint64_t)j * kHistThreads + tid;
     };
     uint4 A = *vptr(cur, 0), B = *vptr(cur, 1);
     while (cur < nfullchunks) {
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
   const uint32_t g0 = fast ? (blockIdx.x == 0 ? nfullchunks : nchunks) : blockIdx.x;
   const uint32_t gstep = fast ? nchunks : gridDim.x;
   for (uint32_t c = g0; c < nchunks; c += gstep) {
-    const uint64_t base = (uint64_t)c << chunk_log2;
+    const uint64_t base = (uint64_t)c * chunk;
     const uint64_t len = (n - base < chunk) ? (n - base) : chunk;
     const uint8_t* p = in + base;
     uint32_t head = (uint32_t)((16u - (uint32_t)((uintptr_t)p & 15u)) & 15u);
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
   }
 }
 
-void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, uint32_t* d_chunk_hist,
+void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk, uint32_t nchunks, uint32_t* d_chunk_hist,
                       uint64_t* d_hist, uint64_t* d_acc, hipStream_t s) {
   // one resident round of workgroups, 4 per CU: measured faster than the 5 the LDS would allow (2 GiB stream:
   // 5.55 TB/s at 1024 workgroups vs 4.95 TB/s at 1280 -- the fifth workgroup only adds L2/LDS pressure)
@@ -175,7 +174,7 @@ void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint
   uint32_t grid = (uint32_t)(4 * ncu);
   if (grid > nchunks) grid = nchunks;
   if (grid == 0) grid = 1;
-  hipLaunchKernelGGL(k_histogram, dim3(grid), dim3(kHistThreads), 0, s, d_in, n, chunk_log2, nchunks, d_chunk_hist,
+  hipLaunchKernelGGL(k_histogram, dim3(grid), dim3(kHistThreads), 0, s, d_in, n, chunk, nchunks, d_chunk_hist,
                      reinterpret_cast<unsigned long long*>(d_hist), reinterpret_cast<unsigned long long*>(d_acc));
 }
 
@@ -810,7 +809,7 @@ __global__ __launch_bounds__(256) void k_chunk_bits(const uint32_t* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void k_chunk_bits_direct(const uint8_t* __restrict__ in, uint64_t n, uint32_t chunk_log2,
+__global__ __launch_bounds__(256) void k_chunk_bits_direct(const uint8_t* __restrict__ in, uint64_t n, uint32_t chunk32,
                                                            uint32_t nchunks, const ghf_code* __restrict__ code,
                                                            uint64_t* __restrict__ bits) {
   __shared__ uint32_t ll[256];
@@ -819,9 +818,9 @@ __global__ __launch_bounds__(256) void k_chunk_bits_direct(const uint8_t* __rest
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  const uint64_t chunk = 1ull << chunk_log2;
+  const uint64_t chunk = chunk32;
   for (uint32_t c = wave; c < nchunks; c += nwaves) {
-    const uint64_t base = (uint64_t)c << chunk_log2;
+    const uint64_t base = (uint64_t)c * chunk;
     const uint64_t len = (n - base < chunk) ? (n - base) : chunk;
     unsigned long long b = 0;
     for (uint64_t i = lane; i < len; i += 64) b += ll[in[base + i]];
@@ -894,7 +893,7 @@ void launch_scan(uint64_t* d_v, uint32_t count, uint64_t* d_total, hipStream_t s
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_v, count, d_total);
 }
 
-void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t nchunks, const uint32_t* d_chunk_hist,
+void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk, uint32_t nchunks, const uint32_t* d_chunk_hist,
                  const ghf_code* d_code, uint64_t* d_chunk_off, uint64_t* d_total_bits, hipStream_t s) {
   uint32_t blocks = (nchunks + 3) / 4;
   if (blocks > 2048) blocks = 2048;
@@ -902,7 +901,7 @@ void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk_log2, uint32_t 
   if (d_chunk_hist)
     hipLaunchKernelGGL(k_chunk_bits, dim3(blocks), dim3(256), 0, s, d_chunk_hist, nchunks, d_code, d_chunk_off);
   else
-    hipLaunchKernelGGL(k_chunk_bits_direct, dim3(blocks), dim3(256), 0, s, d_in, n, chunk_log2, nchunks, d_code,
+    hipLaunchKernelGGL(k_chunk_bits_direct, dim3(blocks), dim3(256), 0, s, d_in, n, chunk, nchunks, d_code,
                        d_chunk_off);
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_chunk_off, nchunks, d_total_bits);
 }
