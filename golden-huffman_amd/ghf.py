@@ -172,6 +172,14 @@ def lib():
     return L
 
 
+def lib_identity():
+    """path and sha256 of the library this process bound (bench.py prints it)"""
+    import hashlib
+
+    with open(LIB_PATH, "rb") as f:
+        return {"path": os.path.relpath(LIB_PATH, os.path.dirname(_HERE)), "sha256": hashlib.sha256(f.read()).hexdigest()}
+
+
 def compress_bound(n):
     return int(lib().ghf_compress_bound(n))
 
@@ -231,6 +239,10 @@ class Context:
     def use_current_stream(self):
         s = self.torch.cuda.current_stream(self.device).cuda_stream
         self._chk(self.L.ghf_ctx_set_stream(self.h, C.c_void_p(s)), "ghf_ctx_set_stream")
+
+    def use_stream(self, stream):
+        """queue on the given torch.cuda.Stream (no change of torch's current stream)"""
+        self._chk(self.L.ghf_ctx_set_stream(self.h, C.c_void_p(stream.cuda_stream)), "ghf_ctx_set_stream")
 
     def close(self):
         if getattr(self, "h", None):

@@ -256,8 +256,9 @@ def have_ref():
     return os.path.exists(REF_BIN)
 
 
-def ref_run(args, timeout=120):
+def ref_run(args, timeout=120, cpu=None):
     """run oracle/_ref/ref_glzip under a timeout and an output-size limit (a runaway
-    reference decoder fills the disk)."""
+    reference decoder fills the disk); cpu = pin the process to that one core (the reference is single-threaded)."""
     cmd = "ulimit -f 16777216; exec '%s' %s" % (REF_BIN, " ".join("'%s'" % a for a in args))
-    return subprocess.run(["bash", "-c", cmd], check=True, timeout=timeout, capture_output=True, text=True).stdout
+    pin = (lambda: os.sched_setaffinity(0, {cpu})) if cpu is not None else None
+    return subprocess.run(["bash", "-c", cmd], check=True, timeout=timeout, capture_output=True, text=True, preexec_fn=pin).stdout

@@ -5,7 +5,7 @@ set -e
 R=$(cd $(dirname $0)/.. && pwd)
 P=$R/golden-huffman_amd
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -mllvm -amdgpu-atomic-optimizer-strategy=None -I$R/include -I$P/csrc"
-mkdir -p $R/scratch/exp
+rm -rf $R/scratch/exp; mkdir -p $R/scratch/exp
 build() {  # name, sed script for ghf_decode.hip, sed script for ghf_emit.hip
   T=$(mktemp -d /tmp/ghf_ab.XXXX)
   cp $P/csrc/*.hip $P/csrc/*.h $T/
@@ -16,16 +16,14 @@ build() {  # name, sed script for ghf_decode.hip, sed script for ghf_emit.hip
   echo built $1
 }
 build base "" "" &
-# K7: no table lookup (entry from the window bits: 8/9-bit code lengths like uniform data) -> how much is LDS lookup latency
-build nolut 's|return \*reinterpret_cast<const uint32_t\*>(T.base + ((v >> T.lsh) << T.ash));|return (v >> 24) \| ((8u + (v >> 31)) << 8);|' "" &
-# K7: refills do not read LDS
-build norefill 's|    nextw = in_word(lin, la);  \\|    nextw = nextw * 2654435761u + la;  \\|' "" &
+# K5: no unit stores (LDS work stays)
+build emit_nostore "" 's|      W.out_units\[W.unit_base + j\] = v;|      if (v.x == 0x12345678u \&\& v.y == 0x9abcdef0u) W.out_units[W.unit_base + j] = v;|' &
+# K5: no manual drain
+build emit_nodrain "" 's|  if (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F71);  // vmcnt(1)||' &
 wait
-# K7: no output stores (copy-out reads stay)
-build nostore 's|\*reinterpret_cast<uint4\*>(og + r \* 1024) = \*reinterpret_cast<const uint4\*>(tile + sl \* 16 + piece \* 4);|{ const uint4 t_ = *reinterpret_cast<const uint4*>(tile + sl * 16 + piece * 4); if (t_.x == 0x12345678u \&\& t_.y == 0x9abcdef0u) *reinterpret_cast<uint4*>(og + r * 1024) = t_; }|' "" &
-# K7: no decode at all (pipeline only): out = window words
-build nodecode 's|        else if (VAR == 2) acc = dec_hot<3>(lin, la0, T1, cur.pos, out, used);|        else if (VAR == 2) { for (int d_ = 0; d_ < 16; ++d_) out[d_] = in_word(lin, la0 + 4u * (uint32_t)(ln * 16 + d_)); used = cur.expect; acc = 0; }|' "" &
-# K5: deposits without LDS atomics (plain stores of W0 only) -> LDS conflict cost
-build emit_nodep "" 's|  atomicOr(w + 1, alignbit(hi, lo, s));||; s|  atomicOr(w + 2, alignbit(lo, 0u, s));||' &
+# K5: tile loads replaced by arithmetic (no global reads in the main loop)
+build emit_noload "" 's|        A = pv\[nx \* 64\];|        A = make_uint4(v.x * 2654435761u + 1u, v.y + 7u, v.z ^ v.x, v.w + 3u);|; s|        B = pv\[nx \* 64\];|        B = make_uint4(v.x * 2654435761u + 1u, v.y + 7u, v.z ^ v.x, v.w + 3u);|' &
+# K5: no side-car stores
+build emit_noseg "" 's|  if (seg_dst) \*seg_dst = seg_base + incl;  // side-car: where this lane.s segment ends, relative to its block||' &
 wait
-ls -la $R/scratch/exp/
+ls $R/scratch/exp/
