@@ -369,6 +369,25 @@ def main():
                                          for k, v in cand.items() if v[1] > 0}},
             "library": ghf.lib_identity(),
         }
+        if world == 1:
+            # the decode path a stream WITHOUT side-car takes (a .crs2 the reference wrote; what Decompressor<...>::decompress()
+            # of the C++ host layer runs): K6 rebuilds the side-car on the GPU, then K7.  Host wall time: K6 looks at a
+            # convergence word from the host a few times.
+            cx = ctxs[0]
+            cx.use_stream(main)
+            cx.decode(out, comp_bytes, codes[0], None, d_out=dec, cap=n, nbytes=t_nbytes)
+            torch.cuda.synchronize()
+            reps = 5
+            tf0 = time.perf_counter()
+            for _ in range(reps):
+                cx.decode(out, comp_bytes, codes[0], None, d_out=dec, cap=n, nbytes=t_nbytes)
+            torch.cuda.synchronize()
+            tf = (time.perf_counter() - tf0) / reps
+            cx.sync()
+            ok_f = int(t_nbytes.item()) == n and (args.no_verify or bool((dec[:n] == d_in).all().item()))
+            res["decode_foreign"] = {"GBps": round(n / tf / 1e9, 3), "ms": round(tf * 1e3, 4), "round_trip_ok": bool(ok_f),
+                                     "vs_indexed_decode": round(tf * 1e3 / stage_ms["decode"], 2) if stage_ms["decode"] else None,
+                                     "what": "ghf_decode(index = NULL): K6 side-car reconstruction + K7, host wall time per stream"}
         if world > 1 and args.backend == "nccl":
             try:
                 res["config"]["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())

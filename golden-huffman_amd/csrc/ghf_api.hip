@@ -490,27 +490,29 @@ int ghf_parse_header(const uint8_t* h, size_t n, ghf_code* code, size_t* header_
 // K6: rebuild the side-car of a stream that came without one (e.g. a .crs2 written by the reference).
 // Synchronises with the host a few times (convergence flag, symbol count); fills c->fidx.
 static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, size_t hdr, uint64_t end_bit, int mode,
-                            size_t cap, uint32_t first_start = 0, uint64_t* landing = nullptr, int* has_end_mark = nullptr);
+                            size_t cap, uint32_t first_start = 0, uint64_t* landing = nullptr, int* has_end_mark = nullptr,
+                            bool prefer_scan = false);
 
 static int rebuild_index(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code, size_t cap) {
   ghf_code* hc = new (std::nothrow) ghf_code;
   if (!hc) return GHF_E_NOMEM;
   hipError_t e = hipMemcpyAsync(hc, d_code, sizeof(ghf_code), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  const int max_len = hc->max_len;
+  const int max_len = hc->max_len, min_len = hc->min_len;
   delete hc;
   if (e != hipSuccess) return fail(c, GHF_E_HIP, "copy tables to host", e);
   if (max_len < 1 || max_len > 32) return fail(c, GHF_E_FORMAT, "bad max_len in tables");
   const size_t hdr = ghf_header_bytes(max_len);
   if (stream_bytes <= hdr) return fail(c, GHF_E_FORMAT, "stream shorter than its header");
-  return rebuild_index_at(c, d_stream, stream_bytes, hdr, (uint64_t)stream_bytes * 8, 0, cap);
+  return rebuild_index_at(c, d_stream, stream_bytes, hdr, (uint64_t)stream_bytes * 8, 0, cap, 0, nullptr, nullptr,
+                          /*prefer_scan=*/max_len - min_len <= 1);
 }
 
 // K6 driver.  hdr = bytes in front of the first code; end_bit = one past the last bit that may belong to a code;
 // mode 0: .crs2 (ends with the end mark); 1: .crs (no end mark, must end exactly at end_bit); 2: a piece of a .crs2
 // whose first code boundary is assumed first_start bits behind hdr and whose last code may run past end_bit
 static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, size_t hdr, uint64_t end_bit, int mode,
-                            size_t cap, uint32_t first_start, uint64_t* landing, int* has_end_mark) {
+                            size_t cap, uint32_t first_start, uint64_t* landing, int* has_end_mark, bool prefer_scan) {
   const bool no_eof = mode == 1;
   SyncParams p;
   p.stream = d_stream;
@@ -529,7 +531,7 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
     return o;
   };
   const size_t o_start = carve((p.nsub + 1) * 2), o_used = carve(p.nsub * 2), o_cnt = carve(p.nsub * 4), o_eof = carve(p.nsub),
-               o_tile = carve((ntiles + 2) * 8);
+               o_tile = carve((ntiles + 2) * 8), o_scan = carve(sync_scan_workspace(p.nsub));
   if (off > c->sync_cap) {
     if (c->d_sync) (void)hipFree(c->d_sync);
     c->d_sync = nullptr;
@@ -554,14 +556,35 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
   GHF_HIP(c, hipMemsetAsync(p.used, 0xFF, p.nsub * 2, c->stream));
   GHF_HIP(c, hipMemsetAsync(p.eof, 0, p.nsub, c->stream));
   launch_store_u64(p.eof_sub, nullptr, p.nsub, c->stream);  // "none found"; k_sync_eof takes the minimum
-  // passes until no boundary guess moves (self-synchronisation: a handful of passes in practice)
-  for (uint64_t pass = 0;; ++pass) {
-    if (pass > p.nsub + 2) return fail(c, GHF_E_CORRUPT, "self-synchronisation did not converge");
-    GHF_HIP(c, hipMemsetAsync(p.changed, 0, 8, c->stream));
-    launch_sync_pass(p, c->stream);
-    GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 5, p.changed, 8, hipMemcpyDeviceToHost, c->stream));
-    GHF_HIP(c, hipStreamSynchronize(c->stream));
-    if ((uint32_t)c->h_u64[5] == 0) break;
+  // passes until no boundary guess moves (self-synchronisation: a handful of passes in practice).  They are queued in
+  // batches and the host looks at the "something moved" word of a batch's LAST pass only: one round trip per batch instead of
+  // one per pass (a pass that finds nothing to do reads 4 bytes per subsequence and stages nothing)
+  // Streams that self-synchronise slowly (near-fixed-length codes) would need one pass per subsequence of drift: their
+  // boundaries are seeded by the deterministic scan (launch_sync_scan) -- at once when the caller knows the code is of that
+  // kind, otherwise as soon as a first batch of passes has not settled.  The passes then only verify.
+  {
+    constexpr int kBatch = 4;
+    uint64_t passes = 0;
+    bool scanned = first_start != 0;  // (a stream piece entered mid-code: its first boundary is not a start offset the scan covers)
+    if (prefer_scan && !scanned) {
+      launch_sync_scan(p, ws + o_scan, c->stream);
+      scanned = true;
+    }
+    for (;;) {
+      if (passes > p.nsub + 2) return fail(c, GHF_E_CORRUPT, "self-synchronisation did not converge");
+      for (int b = 0; b < kBatch; ++b) {
+        GHF_HIP(c, hipMemsetAsync(p.changed, 0, 8, c->stream));
+        launch_sync_pass(p, c->stream);
+      }
+      passes += kBatch;
+      GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 5, p.changed, 8, hipMemcpyDeviceToHost, c->stream));
+      GHF_HIP(c, hipStreamSynchronize(c->stream));
+      if ((uint32_t)c->h_u64[5] == 0) break;
+      if (!scanned) {
+        launch_sync_scan(p, ws + o_scan, c->stream);
+        scanned = true;
+      }
+    }
   }
   launch_sync_counts(p, c->d_u64 + 3, c->stream);
   GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 3, c->d_u64 + 3, 16, hipMemcpyDeviceToHost, c->stream));

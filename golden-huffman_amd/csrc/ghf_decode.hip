@@ -855,6 +855,177 @@ __global__ __launch_bounds__(kDecThreads) void k_sync_pass(SyncParams P) {
   }
 }
 
+// ---- K6 for streams that do not self-synchronise quickly (near-fixed-length codes: uniform bytes have 8/9-bit codes and a
+// decoder started at a wrong bit needs ~1000 symbols to fall into step, so the fixed-point passes above advance a few
+// subsequences per launch).  Deterministic instead: for every 2048-bit SUPER-subsequence the landing offset of EVERY
+// possible start offset (a code straddles a boundary by less than max_len <= 32 bits) is one small function; where the
+// true decode enters each super-subsequence is the running composition of those functions -- a parallel scan over function
+// composition (64-ary tree: reduce up, apply down).  The result only seeds start[]: the fixed-point passes then verify it
+// in one pass (and would repair it), so no format subtlety (end mark, .crs end, stream pieces) lives here.
+constexpr int kSupSubs = 4;
+constexpr int kSupBits = kSupSubs * kSubBits;
+constexpr int kFnStride = 32;  // bytes per landing function: entry s = landing offset in the next super-subsequence
+
+__global__ __launch_bounds__(kDecThreads) void k_sync_table(SyncParams P, uint64_t nsup, uint8_t* __restrict__ tab) {
+  __shared__ DecLds L;
+  const int tid = threadIdx.x;
+  dec_lds_load(L, P.dt, tid, kDecThreads);
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
+  const uint64_t ngroups = (P.nsub + 63) >> 6;  // 64 subsequences = 16 super-subsequences per wave trip
+  const uint64_t body_bits = P.end_bit - P.body_bit0;
+  uint32_t* in = L.in[wave];
+  for (uint64_t g = (uint64_t)blockIdx.x * kDecWaves + wave; g < ngroups; g += (uint64_t)gridDim.x * kDecWaves) {
+    wave_sync();
+    const uint64_t base = stage_subs(P, g * 64, in, lane);
+    wave_sync();
+    const uint64_t sup = g * 16 + (uint64_t)(lane & 15);
+    if (sup >= nsup) continue;
+    const uint64_t limit = body_bits - g * 64 * kSubBits;  // end of the stream, relative to the wave's first subsequence
+    const uint64_t lo = (uint64_t)(lane & 15) * kSupBits, hi = lo + kSupBits;
+    for (uint32_t s = (uint32_t)lane >> 4; s < (uint32_t)max_len; s += 4) {  // four lanes share a super-subsequence
+      uint64_t pos = lo + s;
+      BitReader br;
+      br.init(in, base + pos);
+      while (pos < hi && pos < limit) {
+        uint32_t len;
+        (void)dec_any(L, br.hi(), lut_bits, max_len, len);
+        br.skip(len);
+        pos += len;
+      }
+      tab[sup * kFnStride + s] = pos >= hi ? (uint8_t)(pos - hi) : (uint8_t)0;
+    }
+  }
+}
+
+// one level up: out[t] = f[64 t + 63] o ... o f[64 t]  (entry s: where a decode that enters tile t at offset s leaves it)
+__global__ __launch_bounds__(64) void k_fn_reduce(const uint8_t* __restrict__ f, uint64_t n, uint8_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint8_t fl[64 * kFnStride];
+  const uint64_t t = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint64_t first = t * 64;
+  const int cnt = (int)((n - first < 64) ? (n - first) : 64);
+  for (int i = lane; i < cnt * kFnStride / 16; i += 64)
+    reinterpret_cast<uint4*>(fl)[i] = reinterpret_cast<const uint4*>(f + first * kFnStride)[i];
+  __syncthreads();
+  if (lane < kFnStride) {
+    uint32_t cur = (uint32_t)lane;
+    for (int j = 0; j < cnt; ++j) cur = fl[j * kFnStride + (cur & (kFnStride - 1))];
+    out[t * kFnStride + lane] = (uint8_t)cur;
+  }
+}
+
+// one level down: start[64 t + j] = offset at which the true decode enters element j of tile t, given where it enters the tile
+__global__ __launch_bounds__(64) void k_fn_apply(const uint8_t* __restrict__ f, uint64_t n, const uint8_t* __restrict__ tile_start,
+                                                 uint8_t* __restrict__ start) {
+  __shared__ __attribute__((aligned(16))) uint8_t fl[64 * kFnStride];
+  __shared__ uint8_t st[64];
+  const uint64_t t = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint64_t first = t * 64;
+  const int cnt = (int)((n - first < 64) ? (n - first) : 64);
+  for (int i = lane; i < cnt * kFnStride / 16; i += 64)
+    reinterpret_cast<uint4*>(fl)[i] = reinterpret_cast<const uint4*>(f + first * kFnStride)[i];
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t cur = tile_start ? tile_start[t] : 0u;
+    for (int j = 0; j < cnt; ++j) {
+      st[j] = (uint8_t)cur;
+      cur = fl[j * kFnStride + (cur & (kFnStride - 1))];
+    }
+  }
+  __syncthreads();
+  if (lane < cnt) start[first + lane] = st[lane];
+}
+
+// seed start[] of the four subsequences of every super-subsequence from the offset at which the true decode enters it
+__global__ __launch_bounds__(kDecThreads) void k_sync_fill(SyncParams P, uint64_t nsup, const uint8_t* __restrict__ sup_start) {
+  __shared__ DecLds L;
+  const int tid = threadIdx.x;
+  dec_lds_load(L, P.dt, tid, kDecThreads);
+  __syncthreads();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
+  const uint64_t ngroups = (P.nsub + 63) >> 6;
+  const uint64_t body_bits = P.end_bit - P.body_bit0;
+  uint32_t* in = L.in[wave];
+  for (uint64_t g = (uint64_t)blockIdx.x * kDecWaves + wave; g < ngroups; g += (uint64_t)gridDim.x * kDecWaves) {
+    wave_sync();
+    const uint64_t base = stage_subs(P, g * 64, in, lane);
+    wave_sync();
+    const uint64_t sup = g * 16 + (uint64_t)lane;
+    if (lane >= 16 || sup >= nsup) continue;
+    const uint64_t limit = body_bits - g * 64 * kSubBits;
+    const uint64_t lo = (uint64_t)lane * kSupBits, hi = lo + kSupBits;
+    const uint64_t sub0 = sup * kSupSubs;
+    const uint32_t s0 = sup_start[sup];
+    if (sub0 != 0) P.start[sub0] = (uint16_t)s0;  // (subsequence 0 keeps the caller's first_start)
+    uint64_t pos = lo + s0, nb = lo + kSubBits;
+    uint32_t k = 1;
+    BitReader br;
+    br.init(in, base + pos);
+    while (pos < hi && pos < limit && k < (uint32_t)kSupSubs) {
+      uint32_t len;
+      (void)dec_any(L, br.hi(), lut_bits, max_len, len);
+      br.skip(len);
+      pos += len;
+      if (pos >= nb) {  // (a code is shorter than a subsequence: at most one boundary per code)
+        if (sub0 + k < P.nsub) P.start[sub0 + k] = (uint16_t)(pos - nb);
+        ++k;
+        nb += kSubBits;
+      }
+    }
+  }
+}
+
+size_t sync_scan_workspace(uint64_t nsub) {
+  uint64_t n = (nsub + kSupSubs - 1) / kSupSubs, total = 0;
+  for (;;) {
+    total += n;
+    if (n <= 1) break;
+    n = (n + 63) / 64;
+  }
+  return (size_t)(total * (kFnStride + 1) + 256 * 16);  // functions + entry offsets of every level, each level 256-aligned
+}
+
+void launch_sync_scan(const SyncParams& p, uint8_t* ws, hipStream_t s) {
+  const uint64_t nsup = (p.nsub + kSupSubs - 1) / kSupSubs;
+  if (nsup == 0) return;
+  // carve: functions of level 0.., then entry offsets of level 0..
+  uint64_t cnt[16];
+  uint8_t* fn[16];
+  uint8_t* st[16];
+  int levels = 0;
+  uint8_t* q = ws;
+  for (uint64_t n = nsup;; n = (n + 63) / 64) {
+    cnt[levels] = n;
+    fn[levels] = q;
+    q += (n * kFnStride + 255) & ~(uint64_t)255;
+    ++levels;
+    if (n <= 1 || levels == 16) break;
+  }
+  for (int l = 0; l < levels; ++l) {
+    st[l] = q;
+    q += (cnt[l] + 255) & ~(uint64_t)255;
+  }
+  const uint64_t groups = (p.nsub + 63) / 64;
+  uint64_t blocks = (groups + kDecWaves - 1) / kDecWaves;
+  if (blocks > 256 * 5) blocks = 256 * 5;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_sync_table, dim3((uint32_t)blocks), dim3(kDecThreads), 0, s, p, nsup, fn[0]);
+  for (int l = 0; l + 1 < levels; ++l)
+    hipLaunchKernelGGL(k_fn_reduce, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], fn[l + 1]);
+  // the top level has one element: the whole body, entered at offset 0 of its first super-subsequence.  (A piece of a stream
+  // whose first code boundary is first_start bits in: that offset is start[0], below max_len by construction.)
+  hipLaunchKernelGGL(k_fn_apply, dim3(1), dim3(64), 0, s, fn[levels - 1], cnt[levels - 1], (const uint8_t*)nullptr, st[levels - 1]);
+  for (int l = levels - 2; l >= 0; --l)
+    hipLaunchKernelGGL(k_fn_apply, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], st[l + 1], st[l]);
+  hipLaunchKernelGGL(k_sync_fill, dim3((uint32_t)blocks), dim3(kDecThreads), 0, s, p, nsup, st[0]);
+}
+
 // first subsequence that holds the end mark (valid once the passes have converged)
 __global__ __launch_bounds__(256) void k_sync_eof(SyncParams P) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;

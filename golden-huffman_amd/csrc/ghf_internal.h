@@ -127,6 +127,9 @@ struct SyncParams {
 // kernel launchers (ghf_kernels.hip); all asynchronous on `s`
 void launch_sync_pass(const SyncParams& p, hipStream_t s);
 void launch_sync_counts(const SyncParams& p, uint64_t* d_total, hipStream_t s);
+// deterministic seeding of p.start[] (function-composition scan); ws = sync_scan_workspace(p.nsub) bytes, 256-byte aligned
+size_t sync_scan_workspace(uint64_t nsub);
+void launch_sync_scan(const SyncParams& p, uint8_t* ws, hipStream_t s);
 void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_symbols, uint64_t* d_chunk_bit, uint32_t* d_seg_bit,
                        hipStream_t s);
 // K1 scratch, all zero between launches: 32 replicas of the 256 totals, the arrival counter (word 8192), 16 ticket

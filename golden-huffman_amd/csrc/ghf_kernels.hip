@@ -255,78 +255,96 @@ __device__ __forceinline__ u64t heap_pop(HeapLds& h, int& n) {
 
 // ---- the same two heap operations, executed by the WHOLE wave in a constant number of steps ----
 // A sift only ever touches one root-to-leaf path, and libstdc++'s __adjust_heap picks that path from
-// sibling comparisons alone (the value being re-inserted plays no part until the final __push_heap).  So:
-//   1. every lane compares the two children of "its" internal nodes -> two ballots = a 128-bit map of
-//      preferred children for the whole heap;
-//   2. the scalar unit follows the map from the root to a leaf (bit tests, no memory);
-//   3. lane j loads the entry at depth j of that path; one ballot against the re-inserted value tells where
-//      __push_heap stops; lanes shift their entries up by one (DPP) and one lane drops the value in.
-// Identical result to the sequential code above, ~2.5x fewer cycles per pop; heap_pop/heap_sift_up stay as
-// the executable specification (GHF_K2_SEQUENTIAL builds use them).
-__device__ __forceinline__ u64t lane_above(u64t x) {  // value held by lane + 1 (same row of 16 lanes)
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, 0x101, 0xF, 0xF, false);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), 0x101, 0xF, 0xF, false);
-  return ((u64t)hi << 32) | lo;
-}
-
+// sibling comparisons alone (the value being re-inserted plays no part until the final __push_heap).  With
+// 1-based node numbers t (slot[t]; children 2t and 2t+1 sit on one 16-byte boundary), lane l OWNS the
+// children of nodes l and 64 + l (lane 0: nodes 128 and 64) -- 128 parents cover a heap of 257 entries:
+//   1. ONE LDS round trip: every lane loads the children pairs of its two nodes; root and last entry are
+//      read along.  Two ballots = a 128-bit map "preferred child is the right one" for the whole heap;
+//   2. the scalar unit follows the map from the root down: t = 2t + bit[t], two or three scalar
+//      instructions a level, no memory;
+//   3. everything the pop has to move is ALREADY in registers: the entry that moves up into path node u is
+//      u's preferred child, held by u's owner.  Every lane checks whether its nodes are on the path
+//      (t_leaf >> shift == u), one ballot against the re-inserted value tells where __push_heap stops, and
+//      the owners store: slot[u] = child entry above the stop, slot[stop] = value.
+// Identical result to the sequential code above in a third of its time; heap_pop/heap_sift_up stay as the
+// executable specification.
 __device__ __forceinline__ u64t wave_uniform(u64t x) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32));
   return ((u64t)hi << 32) | lo;
 }
 
+__device__ __forceinline__ u64t lane_above(u64t x) {  // value held by lane + 1 (same row of 16 lanes)
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, 0x101, 0xF, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), 0x101, 0xF, 0xF, false);
+  return ((u64t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ u64t wave_heap_pop(HeapLds& h, int& n, int lane) {
-  const int len = n - 1;
+  const int len = __builtin_amdgcn_readfirstlane(n) - 1;  // entries left behind (wave-uniform: keeps the walk on the scalar unit)
   n = len;
+  const uint32_t tA = lane ? (uint32_t)lane : 128u, tB = 64u + (uint32_t)lane;
+  const U64x2 ca = *reinterpret_cast<const U64x2*>(&h.slot[2 * tA]);
+  const U64x2 cb = *reinterpret_cast<const U64x2*>(&h.slot[2 * tB]);
   const u64t top = wave_uniform(h.slot[1]);
   if (len < 1) return top;
-  const u64t value = wave_uniform(h.slot[len + 1]);
-  const int lim = (len - 1) >> 1;
-  // 1. preferred child of every internal node (nodes lane and lane + 64): 1 = left
-  const U64x2 c0 = *reinterpret_cast<const U64x2*>(&h.slot[2 * lane + 2]);
-  const U64x2 c1 = *reinterpret_cast<const U64x2*>(&h.slot[2 * (lane + 64) + 2]);
-  const unsigned long long m0 = __ballot(heap_gt(c0.y, c0.x));
-  const unsigned long long m1 = __ballot(heap_gt(c1.y, c1.x));
-  // 2. walk (scalar).  With D = depth of the last position, every node above depth D-1 has two children, so the
-  //    first D-1 steps need no bounds test, and all of them but a possible 7th stay below node 63 (map m0 only).
+  const u64t value = wave_uniform(h.slot[len + 1]);  // the old last entry, re-inserted from the hole
+  // 1. "go right" = !comp(right, left) (libstdc++ takes the LEFT child when freq[right] > freq[left])
+  const unsigned long long R0 = __ballot(!heap_gt(ca.y, ca.x));  // bit l = node l (l >= 1), bit 0 = node 128
+  const unsigned long long R1 = __ballot(!heap_gt(cb.y, cb.x));  // bit l = node 64 + l
+  // 2. walk.  0-based: while (hole < (len - 1) / 2) -> child; 1-based t = hole + 1: while (t <= lim).  With D = depth of
+  //    the last position, every node above depth D-1 has two children: the first D-1 steps need no bounds test.
+  const uint32_t lim = (uint32_t)(len - 1) >> 1;
   const int D = 31 - __clz(len);
-  const int steps = D - 1;
-  int hole = 0, k = 0;
+  // seven levels unconditionally (two scalar instructions each), then cut the path back to its first D-1 steps: the
+  // prefix of a longer walk IS the shorter walk (what lies below may be stale slots; it is shifted out)
+  uint32_t t = 1;
 #pragma unroll
-  for (int d = 0; d < 6; ++d) {
-    if (d < steps) {
-      hole = 2 * hole + 2 - (int)((m0 >> hole) & 1ull);
-      k = d + 1;
-    }
+  for (int d = 0; d < 6; ++d) t = 2u * t + (uint32_t)((R0 >> t) & 1ull);  // nodes 1..63
+  t = 2u * t + (uint32_t)((R1 >> (t & 63u)) & 1ull);                      // nodes 64..127
+  const int steps = D - 1 > 0 ? D - 1 : 0;
+  t >>= 7 - steps;
+  if (t <= lim) t = 2u * t + (uint32_t)(((t < 64u || t == 128u ? R0 : R1) >> (t & 63u)) & 1ull);  // depth D-1 where both children exist
+  if ((len & 1) == 0 && t == (uint32_t)len >> 1) t = 2u * t;  // lone left child of an even-length heap
+  const int k = 31 - __clz(t);  // depth of the hole
+  // 3. my nodes on the path?  node u at depth j < k is, iff t >> (k - j) == u; its path child is bit (k - j - 1) of t
+  auto on_path = [&](uint32_t u, const U64x2& c, u64t& cv, uint32_t& child) -> bool {
+    const int j = 31 - __clz(u);
+    const bool on = j < k && (t >> (k - j)) == u;
+    const uint32_t bit = on ? (t >> (k - j - 1)) & 1u : 0u;
+    cv = bit ? c.y : c.x;
+    child = 2u * u + bit;
+    return on;
+  };
+  u64t cvA, cvB;
+  uint32_t chA, chB;
+  const bool onA = on_path(tA, ca, cvA, chA), onB = on_path(tB, cb, cvB, chB);
+  // __push_heap from the hole: entries move back down while comp(entry, value); it stops at the deepest path entry with
+  // !comp.  Depth order = node order: node 128 (bit 0 of the A ballot) deepest, then nodes 64..127, then 63..1
+  const unsigned long long SA = __ballot(onA && !heap_gt(cvA, value));
+  const unsigned long long SB = __ballot(onB && !heap_gt(cvB, value));
+  int m = 0;  // depth of the entry that receives `value`
+  if (SA & 1ull) m = 8;
+  else if (SB) m = 7;
+  else if (SA >> 1) m = (31 - __clz((uint32_t)(63 - __clzll((long long)SA)))) + 1;
+  if (onA) {
+    const int j = 31 - __clz(tA);
+    if (j < m) h.slot[tA] = cvA;
+    if (j + 1 == m) h.slot[chA] = value;
   }
-  if (steps > 6) {  // len >= 256: one step from depth 6 (nodes 63..126)
-    const unsigned long long bit = (hole < 64 ? (m0 >> hole) : (m1 >> (hole - 64))) & 1ull;
-    hole = 2 * hole + 2 - (int)bit;
-    ++k;
+  if (onB) {  // depth 6
+    if (6 < m) h.slot[tB] = cvB;
+    if (7 == m) h.slot[chB] = value;
   }
-  if (hole < lim) {  // depth D-1 -> D where that node has both children
-    const unsigned long long bit = (hole < 64 ? (m0 >> hole) : (m1 >> (hole - 64))) & 1ull;
-    hole = 2 * hole + 2 - (int)bit;
-    ++k;
-  }
-  if ((len & 1) == 0 && hole == ((len - 2) >> 1)) {  // lone left child
-    hole = 2 * hole + 1;
-    ++k;
-  }
-  // 3. lane j <-> depth j of the path
-  const bool on = lane <= k;
-  const int pj = on ? (((hole + 1) >> (k - lane)) - 1) : 0;
-  const u64t e = on ? h.slot[pj + 1] : 0ull;
-  const bool stop = lane >= 1 && on && !heap_gt(e, value);  // __push_heap stops below this entry
-  const unsigned long long sm = __ballot(stop);
-  const int m = sm ? 63 - __clzll((long long)sm) : 0;
-  const u64t up = lane_above(e);
-  if (lane <= m) h.slot[pj + 1] = (lane < m) ? up : value;
+  if (m == 0 && lane == 1) h.slot[1] = value;
+  wave_sync();  // the next heap operation reads, in OTHER lanes, what these lanes stored (without the fence the compiler may
+                // forward a lane's own store to its next load and let the other lanes' load overtake the store)
   return top;
 }
 
 // priority_queue::push(e) onto a heap of n entries: __push_heap from position n
-__device__ __forceinline__ void wave_heap_push(HeapLds& h, int n, u64t e, int lane) {
+__device__ __forceinline__ void wave_heap_push(HeapLds& h, int n_, u64t e, int lane) {
+  const int n = __builtin_amdgcn_readfirstlane(n_);
   const int depth = 31 - __clz(n + 1);  // number of ancestors of position n
   const bool on = lane >= 1 && lane <= depth;
   const int aj = ((n + 1) >> lane) - 1;  // lane 0: n itself
@@ -336,6 +354,7 @@ __device__ __forceinline__ void wave_heap_push(HeapLds& h, int n, u64t e, int la
   const int t = sm ? (__ffsll((long long)sm) - 1) - 1 : depth;  // entries of lanes 1..t move down one level
   const u64t up = lane_above(pe);
   if (lane <= t) h.slot[aj + 1] = (lane < t) ? up : e;
+  wave_sync();
 }
 
 struct CodeLds {  // the small per-length tables of K3; the per-symbol arrays go straight to global memory
