@@ -194,7 +194,7 @@ def main():
     ctx = ghf.Context(local_rank)
     n = args.mib << 20
     d_in = synth.make(torch, args.kind, n, offset=rank * n, device="cuda")
-    bound = ghf.compress_bound(n)
+    bound = ghf.compress_bound(n) if world == 1 else ghf.shard_bound(n)
     out = ctx.empty_u8(bound)
     dec = ctx.empty_u8(n)
     index = ctx.index_alloc(n)
@@ -231,6 +231,22 @@ def main():
     t_nbytes = torch.empty(1, dtype=torch.int64, device="cuda")
     last_rank = rank == world - 1
     emit_flags = (ghf.EMIT_LAST if last_rank else 0) | (ghf.EMIT_REBASE if rank > 0 else ghf.EMIT_HEADER)  # rank 0 writes the header
+
+    # N > 1: the two exchanges go through the C ABI (ghf_comm_*: RCCL called directly, queued on the step's side stream);
+    # torch.distributed only carries the 128-byte ncclUniqueId.  One communicator per side stream.  If that cannot be set
+    # up (or GHF_BENCH_COLLECTIVES=torch), torch.distributed's own collectives on the same stream are used instead.
+    comms, coll_path = None, "none"
+    if world > 1:
+        coll_path = "torch.distributed (%s)" % args.backend
+        if args.backend == "nccl" and os.environ.get("GHF_BENCH_COLLECTIVES", "cabi") == "cabi":
+            try:
+                ids = [ghf.comm_unique_id() if rank == 0 else None for _ in range(NSIDE)]
+                dist.broadcast_object_list(ids, src=0)
+                comms = [ctx.comm_init(ids[j], world, rank) for j in range(NSIDE)]
+                coll_path = "C ABI: ghf_comm_allreduce_hist / ghf_comm_allgather_total (RCCL %s called directly)" % ghf.rccl_version()
+            except Exception as e:
+                comms = None
+                coll_path += " [C-ABI communicator failed: %s]" % repr(e)[:120]
 
     def all_reduce_sum(t):
         if args.backend == "nccl":
@@ -269,15 +285,21 @@ def main():
         side.wait_event(ev_hist[k])
         cx.use_stream(side)
         if world > 1:
-            with torch.cuda.stream(side):
-                timed("allreduce", record, side, lambda: all_reduce_sum(h[:256]))
+            if comms:
+                timed("allreduce", record, side, lambda: cx.comm_allreduce_hist(comms[i % NSIDE], h))
+            else:
+                with torch.cuda.stream(side):
+                    timed("allreduce", record, side, lambda: all_reduce_sum(h[:256]))
         timed("build_code", record, side, lambda: cx.build_code(h, c))
         timed("plan", record, side, lambda: cx.encode_plan(d_in, c, total=t_total[k]))
         cx.decode_prepare(c)  # the decode tables of this code: one tiny kernel less on the main stream
         if world > 1:
             def gather():
-                with torch.cuda.stream(side):
-                    all_gather_1(t_totals[k], t_total[k])
+                if comms:
+                    cx.comm_allgather_total(comms[i % NSIDE], t_total[k], t_totals[k])
+                else:
+                    with torch.cuda.stream(side):
+                        all_gather_1(t_totals[k], t_total[k])
                 cx.shard_start_bit(c, t_totals[k], world, rank, out=t_start[k])
             timed("allgather", record, side, gather)
         ev_ready[k].record(side)
@@ -357,7 +379,7 @@ def main():
                        "baseline_config": "configs[1]" if (world == 1 and args.kind == "uniform" and args.mib == 256) else ("configs[3]" if cfg4 else "configs[3]-style shard"),
                        "bytes_per_gpu": n, "compressed_bytes_per_gpu": comp_bytes, "parallelism": "shard%d" % world,
                        "collectives": "none" if world == 1 else "all_reduce(256 x i64) + all_gather(1 x i64) per step",
-                       "world_size": world, "backend": ("none" if world == 1 else ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (rehearsal)")),
+                       "world_size": world, "collective_path": coll_path, "backend": ("none" if world == 1 else ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (rehearsal)")),
                        "pipeline": "steps software-pipelined, 3 in flight (one ghf context and one side stream each): main stream = histogram of step i+2, emit + decode of step i; side streams, two steps ahead = histogram all-reduce, one-wave code build, chunk pricing, decode tables, offset all-gather"},
             "encode_GBps": round(n * world / (enc_ms * 1e-3) / 1e9, 3), "decode_GBps": round(n * world / (stage_ms["decode"] * 1e-3) / 1e9, 3),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -409,6 +431,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(d_in.cpu().numpy(), args.kind)
         print(json.dumps(res), flush=True)
     ctx.index_free(index)
+    for cm in comms or []:
+        ctx.comm_destroy(cm)
     for cx in reversed(ctxs):
         cx.close()
     if world > 1:

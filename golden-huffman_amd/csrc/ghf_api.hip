@@ -34,6 +34,8 @@ struct ghf_ctx {
   ghf_tree* d_tree = nullptr;   // scratch tree for ghf_crs_compress
   DecTables* d_dt = nullptr;
   const ghf_code* dt_code = nullptr;  // ghf_decode_prepare() built d_dt from these tables; consumed by the next ghf_decode
+  uint64_t* d_totals = nullptr;  // [totals_cap] per-rank body bits (ghf_encode_sharded)
+  int totals_cap = 0;
   uint64_t* d_u64 = nullptr;    // [8] scratch scalars: 0 total_bits, 1..2 end, 3 n_symbols, 4 eof_sub, 5 changed
   uint64_t* h_u64 = nullptr;    // [8] pinned mirror
   // K6 workspace (foreign streams)
@@ -94,9 +96,26 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+// accessors for ghf_comm.hip (the struct stays private to this file)
+int ghf_api_fail(ghf_ctx* c, int code, const char* what) { return fail(c, code, what); }
+hipStream_t ghf_api_stream(ghf_ctx* c) { return c->stream; }
+int ghf_api_device(ghf_ctx* c) { return c->device; }
+uint64_t* ghf_api_scratch_u64(ghf_ctx* c) { return c->d_u64; }
+uint64_t* ghf_api_hist(ghf_ctx* c) { return c->d_hist; }
+uint64_t* ghf_api_totals(ghf_ctx* c, int world) {
+  if (world > c->totals_cap) {
+    if (c->d_totals) (void)hipFree(c->d_totals);
+    c->d_totals = nullptr;
+    c->totals_cap = 0;
+    if (hipMalloc(&c->d_totals, (size_t)(world < 8 ? 8 : world) * sizeof(uint64_t)) != hipSuccess) return nullptr;
+    c->totals_cap = world < 8 ? 8 : world;
+  }
+  return c->d_totals;
+}
+
 extern "C" {
 
-int ghf_version(void) { return 100; }
+int ghf_version(void) { return 200; }
 
 const char* ghf_status_string(int s) {
   switch (s) {
@@ -171,6 +190,7 @@ int ghf_ctx_destroy(ghf_ctx* c) {
   if (c->d_tree) (void)hipFree(c->d_tree);
   if (c->d_dt) (void)hipFree(c->d_dt);
   if (c->d_u64) (void)hipFree(c->d_u64);
+  if (c->d_totals) (void)hipFree(c->d_totals);
   if (c->h_u64) (void)hipHostFree(c->h_u64);
   if (c->d_sync) (void)hipFree(c->d_sync);
   if (c->d_seg_abs) (void)hipFree(c->d_seg_abs);

@@ -101,7 +101,10 @@ EXPORTS = [
     "ghf_chunk_symbols", "ghf_index_alloc", "ghf_index_free", "ghf_parse_header", "ghf_decode", "ghf_decoded_size",
     "ghf_shard_start_bit", "ghf_crs_build_code", "ghf_crs_compress", "ghf_crs_compress_bound", "ghf_crs_parse_header",
     "ghf_crs_decode", "ghf_crs_decoded_size", "ghf_build_code_ex", "ghf_compress_ex", "ghf_sync_piece", "ghf_decode_prepare",
+    "ghf_comm_unique_id", "ghf_comm_init_rank", "ghf_comm_destroy", "ghf_comm_world", "ghf_rccl_version",
+    "ghf_comm_allreduce_hist", "ghf_comm_allgather_total", "ghf_encode_sharded", "ghf_shard_bound",
 ]
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -168,6 +171,16 @@ def lib():
     L.ghf_crs_parse_header.argtypes = [vp, sz, C.POINTER(Tree), C.POINTER(sz)]
     L.ghf_crs_decode.argtypes = [vp, vp, sz, i32, vp, C.POINTER(Index), vp, sz, vp]
     L.ghf_crs_decoded_size.argtypes = [vp, vp, sz, i32, vp, C.POINTER(u64)]
+    L.ghf_comm_unique_id.argtypes = [C.c_char_p]
+    L.ghf_comm_init_rank.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(vp)]
+    L.ghf_comm_destroy.argtypes = [vp]
+    L.ghf_comm_world.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.ghf_rccl_version.argtypes = [C.POINTER(i32)]
+    L.ghf_comm_allreduce_hist.argtypes = [vp, vp, vp]
+    L.ghf_comm_allgather_total.argtypes = [vp, vp, vp, vp]
+    L.ghf_encode_sharded.argtypes = [vp, vp, vp, sz, vp, sz, vp, C.POINTER(Index), vp, vp]
+    L.ghf_shard_bound.argtypes = [sz]
+    L.ghf_shard_bound.restype = sz
     _lib = L
     return L
 
@@ -182,6 +195,25 @@ def lib_identity():
 
 def compress_bound(n):
     return int(lib().ghf_compress_bound(n))
+
+
+def shard_bound(n):
+    """capacity for one shard of a sharded stream (packed with the GLOBAL code: up to 32 bits per symbol)"""
+    return int(lib().ghf_shard_bound(n))
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI: 128 bytes that rank 0 hands to every rank (any transport)"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().ghf_comm_unique_id(buf)
+    if rc:
+        raise GhfError(rc, "ghf_comm_unique_id", "RCCL not available in this process")
+    return buf.raw
+
+
+def rccl_version():
+    v = C.c_int(0)
+    return v.value if lib().ghf_rccl_version(C.byref(v)) == 0 else None
 
 
 def chunk_symbols(n):
@@ -221,6 +253,7 @@ class Context:
     EMIT_REBASE = EMIT_REBASE
     EMIT_HEADER = EMIT_HEADER
     compress_bound = staticmethod(compress_bound)
+    shard_bound = staticmethod(shard_bound)
     parse_header = staticmethod(parse_header)
 
     def __init__(self, device=0):
@@ -379,6 +412,38 @@ class Context:
         self._chk(self.L.ghf_sync_piece(self.h, d_piece.data_ptr(), piece_bytes, first_bit, end_bit, d_code.data_ptr(),
                                         C.byref(landing), C.byref(n), C.byref(eof)), "ghf_sync_piece")
         return landing.value, n.value, bool(eof.value)
+
+    # ---- sharded streams over RCCL, C ABI ------------------------------------------
+    def comm_init(self, unique_id, world, rank):
+        """-> opaque ghf_comm handle (ncclCommInitRank on this context's device)"""
+        h = C.c_void_p()
+        self._chk(self.L.ghf_comm_init_rank(self.h, unique_id, world, rank, C.byref(h)), "ghf_comm_init_rank")
+        return h
+
+    def comm_destroy(self, comm):
+        if comm:
+            self.L.ghf_comm_destroy(comm)
+
+    def comm_allreduce_hist(self, comm, d_hist):
+        self._chk(self.L.ghf_comm_allreduce_hist(self.h, comm, d_hist.data_ptr()), "ghf_comm_allreduce_hist")
+
+    def comm_allgather_total(self, comm, d_total, d_totals):
+        self._chk(self.L.ghf_comm_allgather_total(self.h, comm, d_total.data_ptr(), d_totals.data_ptr()), "ghf_comm_allgather_total")
+
+    def encode_sharded(self, comm, d_in, d_out=None, d_code=None, index=None, n=None):
+        """ghf_encode_sharded: this rank's shard, collectives included, one call. -> dict like sharded.encode_sharded"""
+        n = d_in.numel() if n is None else n
+        if d_out is None:
+            d_out = self.empty_u8(shard_bound(n))
+        if d_code is None:
+            d_code = self.new_code()
+        start = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
+        end = self.torch.zeros(2, dtype=self.torch.int64, device=self.device)
+        self._chk(
+            self.L.ghf_encode_sharded(self.h, comm, d_in.data_ptr(), n, d_out.data_ptr(), d_out.numel(), d_code.data_ptr(),
+                                      None if index is None else C.byref(index), start.data_ptr(), end.data_ptr()),
+            "ghf_encode_sharded")
+        return {"out": d_out, "start_bit": start, "end": end, "code": d_code}
 
     # ---- .crs (SURVEY 8f N3: NormalHuffEncoder / NormalHuffDecoder) ---------------------------
     def new_tree(self):

@@ -55,7 +55,10 @@ def encode_sharded(be, dist, d_in, out=None, index=None, group=None):
     if rank > 0:
         flags |= be.EMIT_REBASE
     if out is None:
-        out = be.empty_u8(be.compress_bound(n))
+        # a shard is packed with the GLOBAL code, which can be far from optimal for it (a uniform shard among
+        # low-entropy ones): compress_bound's 9 bits per symbol only hold for a buffer's own code
+        bound = be.shard_bound(n) if (world > 1 and hasattr(be, "shard_bound")) else be.compress_bound(n)
+        out = be.empty_u8(bound)
     if index is not None:
         index.flags = 0 if rank == world - 1 else 1  # GHF_INDEX_NO_END_MARK: this shard is not followed by the end mark
     if rank == 0:
@@ -69,8 +72,7 @@ def encode_sharded(be, dist, d_in, out=None, index=None, group=None):
 
 def decode_sharded(be, enc, index, d_out=None):
     """Decode this rank's shard from its own local buffer + side-car (embarrassingly parallel)."""
-    nbytes = int(be.compress_bound(enc["n"]))
-    return be.decode(enc["out"], nbytes, enc["code"], index, d_out=d_out)
+    return be.decode(enc["out"], int(enc["out"].numel()), enc["code"], index, d_out=d_out)
 
 
 def gather_stream(be, dist, enc, group=None):

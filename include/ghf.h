@@ -193,6 +193,37 @@ int ghf_sync_piece(ghf_ctx* ctx, const uint8_t* d_piece, size_t piece_bytes, uin
                    const ghf_code* d_code, uint64_t* landing, uint64_t* n_symbols, int* has_end_mark);
 
 /* ------------------------------------------------------------------------------------------------
+ * one stream sharded over the GPUs of a node, one process (or thread) and one ghf_ctx per GPU,
+ * RCCL over xGMI underneath.  The reference has no counterpart (it is single-threaded, single-stream:
+ * include/compressor.h:62-73); what makes the shards ONE .crs2 stream, bit-exact with the single-stream
+ * reference, is a single global code, which costs exactly two latency-bound exchanges:
+ *   all-reduce(sum) of the 256 byte counts   (the end-mark slot [256] stays 1: it must not be summed)
+ *   all-gather of the per-rank body bit totals -> every rank's absolute start bit
+ * ghf_comm wraps an ncclComm_t; the RCCL library is bound at first use (dlopen of the copy the process
+ * already has, e.g. torch's, else librccl.so.1), so single-GPU users need no RCCL at all.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ghf_comm ghf_comm;
+#define GHF_COMM_ID_BYTES 128
+int ghf_comm_unique_id(uint8_t id[GHF_COMM_ID_BYTES]);  /* ncclGetUniqueId: one rank calls it, every rank gets the bytes */
+int ghf_comm_init_rank(ghf_ctx* ctx, const uint8_t id[GHF_COMM_ID_BYTES], int world, int rank, ghf_comm** out);
+int ghf_comm_destroy(ghf_comm* comm);
+int ghf_comm_world(const ghf_comm* comm, int* world, int* rank);
+int ghf_rccl_version(int* version);                     /* ncclGetVersion of the bound library */
+/* the two exchanges, on the context's stream (comm == NULL or world 1: d_totals[0] <- *d_total, nothing else) */
+int ghf_comm_allreduce_hist(ghf_ctx* ctx, ghf_comm* comm, uint64_t* d_hist /* [257], in place */);
+int ghf_comm_allgather_total(ghf_ctx* ctx, ghf_comm* comm, const uint64_t* d_total, uint64_t* d_totals /* [world] */);
+/* This rank's shard of the stream, all of the above in order on the context's stream, no host synchronisation:
+ * K1, all-reduce, K2/K3, K4, all-gather, start bit, K5.  rank 0 writes the header and d_out[0] is stream byte 0;
+ * rank g > 0 writes from stream byte 16 * (start_bit / 128) on (GHF_EMIT_REBASE); the last rank appends the end mark.
+ * cap >= ghf_shard_bound(n): a shard is packed with the GLOBAL code, which may be far from optimal for it.
+ * d_code <- the (identical on every rank) tables; *d_start_bit <- this shard's absolute first bit;
+ * d_end[0..1] <- {absolute end bit, bytes defined in d_out}; index (optional) <- side-car for ghf_decode of the shard
+ * (index->flags is set: GHF_INDEX_NO_END_MARK on every rank but the last). */
+int ghf_encode_sharded(ghf_ctx* ctx, ghf_comm* comm, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap,
+                       ghf_code* d_code, ghf_index* index, uint64_t* d_start_bit, uint64_t* d_end);
+size_t ghf_shard_bound(size_t n); /* header + 4 n (32 bits per symbol) + end mark + alignment slack */
+
+/* ------------------------------------------------------------------------------------------------
  * inputs on which the reference is undefined because a code would be longer than 32 bits
  * (include/canonical_huff_encoder.h:43-44; needs > 14.9 M bytes with Fibonacci-like counts).  With GHF_CODE_LIMIT
  * the code lengths are then replaced by the OPTIMAL lengths under a 32-bit limit (package-merge; leaves ordered by

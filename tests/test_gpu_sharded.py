@@ -46,6 +46,14 @@ class HostStagedDist:
         self.d.barrier()
 
 
+def _shard_data(dg, kind, rank, world, lo, hi):
+    """"hetero": low-entropy shards and ONE uniform shard -- the global code then costs the uniform shard more than
+    9 bits per symbol (what ghf_compress_bound allows for a buffer's own code)"""
+    if kind == "hetero":
+        return dg.make("uniform" if rank == world - 1 else "sym16", hi - lo, seed=9, offset=lo)
+    return dg.make(kind, hi - lo, seed=9, offset=lo)
+
+
 def _worker(rank, world, port, kind, n_total, q):
     import traceback
 
@@ -64,7 +72,7 @@ def _worker(rank, world, port, kind, n_total, q):
         ctx = pkg.ghf.Context(0)
         hd = HostStagedDist(dist)
         lo, hi = rank * n_total // world, (rank + 1) * n_total // world
-        data = dg.make(kind, hi - lo, seed=9, offset=lo)
+        data = _shard_data(dg, kind, rank, world, lo, hi)
         shard = torch.from_numpy(data).cuda()
         index = ctx.index_alloc(shard.numel())
         enc = sharded.encode_sharded(ctx, hd, shard, index=index)
@@ -107,6 +115,73 @@ def test_two_ranks_on_one_gpu(kind, n_total):
     ref = orc.compress(dg.make(kind, n_total, seed=9))
     got_stream = np.frombuffer(stream, dtype=np.uint8)
     assert got_stream.size == ref.size and np.array_equal(got_stream, ref)
+
+
+def test_three_ranks_heterogeneous_shards_on_one_gpu():
+    """two 16-symbol shards and one uniform shard: the uniform one is packed at ~10 bits per symbol"""
+    import datagen as dg
+    from oracle import oracle as orc
+
+    world, n_total, kind = 3, 3 * 400000 + 5, "hetero"
+    port = 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(g[1] for g in got), "a rank failed to decode its own shard: %s" % [g[3] for g in got]
+    whole = np.concatenate([_shard_data(dg, kind, r, world, r * n_total // world, (r + 1) * n_total // world) for r in range(world)])
+    ref = orc.compress(whole)
+    got_stream = np.frombuffer(next(g[2] for g in got if g[2] is not None), dtype=np.uint8)
+    assert got_stream.size == ref.size and np.array_equal(got_stream, ref)
+    # the uniform shard really does not fit compress_bound: that is what shard_bound is for
+    import pkgload
+
+    ghf = pkgload.load().ghf
+    body_bits = 8 * (ref.size - 1040 - 8 * 32)
+    assert body_bits > 0 and ghf.shard_bound(n_total // world) >= 4 * (n_total // world)
+
+
+def test_encode_sharded_c_abi_world1_over_rccl():
+    """ghf_encode_sharded with a REAL RCCL communicator of one rank (ncclCommInitRank through the C ABI): the two
+    collectives are queued on the context's stream; the result is the single-stream .crs2"""
+    import datagen as dg
+    import pkgload
+    from oracle import oracle as orc
+
+    ghf = pkgload.load().ghf
+    assert ghf.rccl_version(), "RCCL not bound"
+    ctx = ghf.Context(0)
+    comm = ctx.comm_init(ghf.comm_unique_id(), 1, 0)
+    try:
+        for kind, n in (("zipf", 1 << 20), ("uniform", 300001)):
+            data = dg.make(kind, n, seed=5)
+            d_in = torch.from_numpy(data).cuda()
+            idx = ctx.index_alloc(n)
+            enc = ctx.encode_sharded(comm, d_in, index=idx)
+            ctx.sync()
+            nb = int(enc["end"][1].item())
+            ref = orc.compress(data)
+            assert nb == ref.size and np.array_equal(enc["out"][:nb].cpu().numpy(), ref)
+            back, _ = ctx.decode(enc["out"], nb, enc["code"], idx)
+            ctx.sync()
+            assert np.array_equal(back[:n].cpu().numpy(), data)
+            ctx.index_free(idx)
+        # the stand-alone collectives: a no-op sum over one rank, a gather of one value
+        h = ctx.histogram(d_in)
+        before = h.clone()
+        ctx.comm_allreduce_hist(comm, h)
+        tot = torch.tensor([12345], dtype=torch.int64, device="cuda")
+        tots = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ctx.comm_allgather_total(comm, tot, tots)
+        ctx.sync()
+        assert bool((h == before).all().item()) and int(tots.item()) == 12345
+    finally:
+        ctx.comm_destroy(comm)
+        ctx.close()
 
 
 def test_bench_two_rank_rehearsal():
