@@ -511,7 +511,7 @@ int ghf_parse_header(const uint8_t* h, size_t n, ghf_code* code, size_t* header_
 // Synchronises with the host a few times (convergence flag, symbol count); fills c->fidx.
 static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, size_t hdr, uint64_t end_bit, int mode,
                             size_t cap, uint32_t first_start = 0, uint64_t* landing = nullptr, int* has_end_mark = nullptr,
-                            bool prefer_scan = false);
+                            bool prefer_scan = false, int max_len_hint = 0);
 
 static int rebuild_index(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code, size_t cap) {
   ghf_code* hc = new (std::nothrow) ghf_code;
@@ -525,14 +525,14 @@ static int rebuild_index(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
   const size_t hdr = ghf_header_bytes(max_len);
   if (stream_bytes <= hdr) return fail(c, GHF_E_FORMAT, "stream shorter than its header");
   return rebuild_index_at(c, d_stream, stream_bytes, hdr, (uint64_t)stream_bytes * 8, 0, cap, 0, nullptr, nullptr,
-                          /*prefer_scan=*/max_len - min_len <= 1);
+                          /*prefer_scan=*/max_len - min_len <= 1, max_len);
 }
 
 // K6 driver.  hdr = bytes in front of the first code; end_bit = one past the last bit that may belong to a code;
 // mode 0: .crs2 (ends with the end mark); 1: .crs (no end mark, must end exactly at end_bit); 2: a piece of a .crs2
 // whose first code boundary is assumed first_start bits behind hdr and whose last code may run past end_bit
 static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, size_t hdr, uint64_t end_bit, int mode,
-                            size_t cap, uint32_t first_start, uint64_t* landing, int* has_end_mark, bool prefer_scan) {
+                            size_t cap, uint32_t first_start, uint64_t* landing, int* has_end_mark, bool prefer_scan, int max_len_hint) {
   const bool no_eof = mode == 1;
   SyncParams p;
   p.stream = d_stream;
@@ -586,8 +586,9 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
     constexpr int kBatch = 4;
     uint64_t passes = 0;
     bool scanned = first_start != 0;  // (a stream piece entered mid-code: its first boundary is not a start offset the scan covers)
+    const uint32_t fn_stride = (max_len_hint >= 1 && max_len_hint <= 16) ? 16u : 32u;
     if (prefer_scan && !scanned) {
-      launch_sync_scan(p, ws + o_scan, c->stream);
+      launch_sync_scan(p, ws + o_scan, fn_stride, c->stream);
       scanned = true;
     }
     for (;;) {
@@ -601,7 +602,7 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
       GHF_HIP(c, hipStreamSynchronize(c->stream));
       if ((uint32_t)c->h_u64[5] == 0) break;
       if (!scanned) {
-        launch_sync_scan(p, ws + o_scan, c->stream);
+        launch_sync_scan(p, ws + o_scan, fn_stride, c->stream);
         scanned = true;
       }
     }

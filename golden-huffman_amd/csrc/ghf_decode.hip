@@ -145,18 +145,6 @@ void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_
   hipLaunchKernelGGL(k_build_decode_tables, dim3(1), dim3(256), 0, s, d_code, d_dt, d_status);
 }
 
-struct DecLds {  // K6 (side-car reconstruction): 4 waves, plain table
-  alignas(16) uint32_t in[kDecWaves][kDecInWords + 4];
-  alignas(16) uint16_t lut[1 << kDecLutBitsMax];
-  uint32_t fcl[36];
-  uint32_t sp[36];
-  uint16_t symbol[GHF_NSYM + 3];
-  uint16_t tl[256], tr[256];  // kind 1 (.crs): the tree
-  uint32_t root;
-  int kind;
-  int status0;
-};
-
 // K7 keeps the direct table in LDS as 32-bit entries, REPLICATED so that the 64 random lookups of a wave do not pile
 // up on a few banks: the table gets 64 KiB = 16384 slots; with lut_bits index bits there is room for
 // R = min(32, 2^(14 - lut_bits)) copies, slot = index * R + lane % R.  Up to 9-bit tables (uniform bytes: 8/9-bit codes)
@@ -210,14 +198,6 @@ __device__ __forceinline__ void dec_small_load(LT& L, const DecTables* dt, int t
     L.kind = dt->kind;
     L.root = dt->root;
   }
-}
-
-__device__ __forceinline__ void dec_lds_load(DecLds& L, const DecTables* dt, int tid, int nthreads) {
-  const int lut_bits = dt->lut_bits;
-  const uint4* src = reinterpret_cast<const uint4*>(dt->lut);
-  uint4* dst = reinterpret_cast<uint4*>(L.lut);
-  for (int i = tid; i < ((1 << lut_bits) * 2 + 15) / 16; i += nthreads) dst[i] = src[i];
-  dec_small_load(L, dt, tid, nthreads);
 }
 
 __device__ __forceinline__ uint32_t dec7_entry(uint32_t g) {  // DecTables::lut entry (sym | len << 9) -> LDS entry
@@ -728,81 +708,108 @@ void launch_decode(const DecParams& p, hipStream_t s) {
 // segmentation; passes repeat (only threads whose guess changed redo work) until nothing changes.
 // Then symbol counts are prefix-summed, the end mark fixes n, and one more pass writes the bit position
 // of every 64th symbol -- the same side-car K5 emits.
+// All K6 kernels run on K7's engine: one 16-wave workgroup per CU, the 64 KiB replicated direct table
+// (conflict-free lookups), padded input tiles (conflict-free window refills); a wave trip = 64
+// subsequences = 4 KiB of stream.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSubBits = 512;
 
-struct BitReader {  // left-justified 64-bit window over big-endian words (LDS)
-  const uint32_t* in;
-  uint32_t widx;
-  uint64_t window;
-  int avail;
-  __device__ __forceinline__ void init(const uint32_t* words, uint64_t pos) {
-    in = words;
-    widx = (uint32_t)(pos >> 5);
-    const uint32_t off = (uint32_t)(pos & 31u);
-    window = (((uint64_t)in[widx] << 32) | in[widx + 1]) << off;
-    widx += 2;
-    avail = 64 - (int)off;
+// this lane's replica of the one-symbol table (K7's T1)
+__device__ __forceinline__ DecLut dec7_lut1(const DecLds7& L, const DecTables* dt, int lane) {
+  const int pair_bits = dt->pair_bits, lut_bits = dt->lut_bits;
+  const int r1 = pair_bits ? 5 : ((kDec7LutLog2 - lut_bits) < 5 ? (kDec7LutLog2 - lut_bits) : 5);
+  const uint32_t* t1 = L.lut + (pair_bits ? kDec7LutSlots : 0);
+  DecLut T;
+  T.base = reinterpret_cast<const char*>(t1 + ((uint32_t)lane & ((1u << r1) - 1u)));
+  T.lsh = 32 - lut_bits;
+  T.ash = r1 + 2;
+  return T;
+}
+
+// a lane's decode cursor over its wave's staged tile: 64-bit window + one word of look-ahead
+struct K6Cursor {
+  uint32_t la;  // logical byte address of the next word to fetch
+  uint64_t W;
+  uint32_t nextw, o;
+  __device__ __forceinline__ void open(const uint8_t* lin, uint32_t la0, uint32_t pos) {
+    la = la0 + ((pos >> 5) << 2);
+    o = pos & 31u;
+    W = ((uint64_t)in_word(lin, la) << 32) | in_word(lin, la + 4u);
+    nextw = in_word(lin, la + 8u);
+    la += 12u;
   }
-  __device__ __forceinline__ uint32_t hi() {
-    if (avail < 32) {
-      window |= (uint64_t)in[widx++] << (32 - avail);
-      avail += 32;
+  // the entry (symbol | length << 8 | flags) of the code at the cursor; the cursor moves behind it.
+  // lut_bits < 0: the caller knows that the direct table resolves every code (max_len <= 12, canonical): no miss path
+  __device__ __forceinline__ uint32_t step(const uint8_t* lin, const DecLds7& L, const DecLut& T, int lut_bits, int max_len) {
+    if (o >= 32u) {
+      W = (W << 32) | nextw;
+      o -= 32u;
+      nextw = in_word(lin, la);
+      la += 4u;
     }
-    return (uint32_t)(window >> 32);
-  }
-  __device__ __forceinline__ void skip(uint32_t len) {
-    window <<= len;
-    avail -= (int)len;
+    const uint32_t v = (uint32_t)((W << o) >> 32);
+    uint32_t ent = dec_lookup(T, v);
+    if (lut_bits >= 0 && (ent & kEntNone)) ent = dec_long_entry(L, v, lut_bits, max_len);
+    o += (ent >> 8) & 0xFFu;
+    return ent;
   }
 };
 
-__device__ __forceinline__ uint32_t dec_any(const DecLds& L, uint32_t hi, int lut_bits, int max_len, uint32_t& len) {
-  const uint32_t ent = L.lut[hi >> (32 - lut_bits)];
-  len = ent >> 9;
-  if (len) return ent & 0x1FFu;
-  const uint32_t r = dec_long(L, hi, lut_bits, max_len);
-  len = r >> 16;
-  return r & 0xFFFFu;
-}
-
-// stage the bits of 64 consecutive subsequences (+ look-ahead) of the body into this wave's LDS words;
-// returns the bit offset of subsequence `sub0` inside the staged words
-__device__ __forceinline__ uint64_t stage_subs(const SyncParams& P, uint64_t sub0, uint32_t* in, int lane) {
+// stage the bits of 64 consecutive subsequences (+ look-ahead) of the body into the wave's padded tile (big-endian
+// words, zeros behind the stream); returns the bit offset of subsequence `sub0` inside the tile
+__device__ __forceinline__ uint32_t k6_stage(const SyncParams& P, uint64_t sub0, uint8_t* lin, uint32_t la0, int lane) {
   const uint64_t bit0 = P.body_bit0 + sub0 * kSubBits;
   const uint64_t byte0 = (bit0 >> 3) & ~15ull;
   uint64_t byte1 = ((bit0 + 64ull * kSubBits + 7) >> 3) + 16;
   if (byte1 > P.stream_bytes) byte1 = P.stream_bytes;
-  const uint64_t span = byte1 > byte0 ? byte1 - byte0 : 0;
+  const uint32_t span = byte1 > byte0 ? (uint32_t)(byte1 - byte0) : 0u;
   const uint8_t* src = P.stream + byte0;
-  for (uint64_t o = (uint64_t)lane * 16; o < span; o += 1024) {
-    uint4 v;
-    if (o + 16 <= span) {
+#pragma unroll
+  for (int k = 0; k < (kDec7TileLog + 1023) / 1024; ++k) {
+    const uint32_t o = (uint32_t)k * 1024u + (uint32_t)lane * 16u;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (o + 16u <= span) {
       v = *reinterpret_cast<const uint4*>(src + o);
-    } else {
+    } else if (o < span) {  // the stream's last, incomplete 16 bytes: byte loads, never past the end of the buffer
       uint32_t q[4] = {0, 0, 0, 0};
       for (uint32_t j = 0; o + j < span; ++j) q[j >> 2] |= (uint32_t)src[o + j] << (8 * (j & 3));
       v = make_uint4(q[0], q[1], q[2], q[3]);
     }
-    *reinterpret_cast<uint4*>(in + (o >> 2)) = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+    if (o + 16u <= (uint32_t)kDec7TileLog)
+      *reinterpret_cast<uint4*>(lin + in_phys(la0 + o)) = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
   }
-  const uint32_t wend = (uint32_t)((span + 15) >> 4) << 2;
-  for (uint32_t k = wend + lane; k < (uint32_t)kDecInWords + 4; k += 64) in[k] = 0;
-  return bit0 - byte0 * 8;
+  return (uint32_t)(bit0 - byte0 * 8);
 }
 
-__global__ __launch_bounds__(kDecThreads) void k_sync_pass(SyncParams P) {
-  __shared__ DecLds L;
-  const int tid = threadIdx.x;
-  dec_lds_load(L, P.dt, tid, kDecThreads);
-  __syncthreads();
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
-  const uint64_t ngroups = (P.nsub + 63) >> 6;
-  const uint64_t body_bits = P.end_bit - P.body_bit0;
-  uint32_t* in = L.in[wave];
-  for (uint64_t g = (uint64_t)blockIdx.x * kDecWaves + wave; g < ngroups; g += (uint64_t)gridDim.x * kDecWaves) {
+constexpr int kK6Threads = kDec7Threads;
+constexpr int kK6Waves = kDec7Waves;
+
+// what every K6 kernel starts with: tables into LDS, this lane's table replica, the wave's tile
+#define GHF_K6_PROLOGUE()                                                  \
+  __shared__ DecLds7 L;                                                    \
+  const int tid = threadIdx.x;                                             \
+  dec_lds_load7(L, P.dt, tid, kK6Threads);                                 \
+  __syncthreads();                                                         \
+  const int lane = tid & 63;                                               \
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               \
+  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;            \
+  const bool direct = P.dt->kind == 0 && max_len <= kDecLutBitsMax;        \
+  const DecLut T1 = dec7_lut1(L, P.dt, lane);                              \
+  uint8_t* const lin = L.in;                                               \
+  const uint32_t la0 = (uint32_t)wave * kDec7TileLog;                      \
+  const uint64_t ngroups = (P.nsub + 63) >> 6;                             \
+  const uint64_t body_bits = P.end_bit - P.body_bit0
+
+__device__ __forceinline__ uint32_t k6_limit(uint64_t body_bits, uint64_t g) {  // end of the stream, relative to the wave's first subsequence
+  const uint64_t l = body_bits - g * 64 * kSubBits;
+  return l > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)l;
+}
+
+__global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
+  GHF_K6_PROLOGUE();
+  auto run = [&](auto direct_tag) {
+  const int lb = decltype(direct_tag)::value ? -1 : lut_bits;
+  for (uint64_t g = (uint64_t)blockIdx.x * kK6Waves + wave; g < ngroups; g += (uint64_t)gridDim.x * kK6Waves) {
     const uint64_t sub = g * 64 + lane;
     const bool valid = sub < P.nsub;
     uint32_t st = 0;
@@ -813,26 +820,24 @@ __global__ __launch_bounds__(kDecThreads) void k_sync_pass(SyncParams P) {
     }
     if (!__ballot(work)) continue;  // the whole wave's results are still current
     wave_sync();
-    const uint64_t base = stage_subs(P, g * 64, in, lane);
+    const uint32_t base = k6_stage(P, g * 64, lin, la0, lane);
     wave_sync();
     if (work) {
-      const uint64_t sub_lo = (uint64_t)lane * kSubBits;  // relative to the wave's first subsequence
-      const uint64_t sub_hi = sub_lo + kSubBits;
-      const uint64_t limit = body_bits - g * 64 * kSubBits;  // end of the stream, same origin
-      uint64_t pos = sub_lo + st;
+      const uint32_t sub_lo = (uint32_t)lane * kSubBits;  // relative to the wave's first subsequence
+      const uint32_t sub_hi = sub_lo + kSubBits;
+      const uint32_t limit = k6_limit(body_bits, g);
+      uint32_t pos = sub_lo + st;
       uint32_t count = 0;
       bool eof = false;
-      BitReader br;
-      br.init(in, base + pos);
+      K6Cursor cur;
+      cur.open(lin, la0, base + pos);
       while (pos < sub_hi && pos < limit) {
-        uint32_t len;
-        const uint32_t sym = dec_any(L, br.hi(), lut_bits, max_len, len);
-        if (sym == 256u) {
+        const uint32_t ent = cur.step(lin, L, T1, lb, max_len);
+        if (ent & kEntEnd) {  // the end mark (or bits that are no code)
           eof = true;
           break;
         }
-        br.skip(len);
-        pos += len;
+        pos += (ent >> 8) & 0xFFu;
         ++count;
       }
       // .crs has no end mark: "eof" then means "this cannot be right" -- a bit pattern that is no code, or a last
@@ -853,157 +858,132 @@ __global__ __launch_bounds__(kDecThreads) void k_sync_pass(SyncParams P) {
       if (P.no_eof == 2u && sub + 1 == P.nsub) P.start[P.nsub] = eof ? (uint16_t)0xFFFF : (uint16_t)(pos - limit);
     }
   }
+  };
+  if (direct) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 // ---- K6 for streams that do not self-synchronise quickly (near-fixed-length codes: uniform bytes have 8/9-bit codes and a
 // decoder started at a wrong bit needs ~1000 symbols to fall into step, so the fixed-point passes above advance a few
-// subsequences per launch).  Deterministic instead: for every 2048-bit SUPER-subsequence the landing offset of EVERY
-// possible start offset (a code straddles a boundary by less than max_len <= 32 bits) is one small function; where the
-// true decode enters each super-subsequence is the running composition of those functions -- a parallel scan over function
-// composition (64-ary tree: reduce up, apply down).  The result only seeds start[]: the fixed-point passes then verify it
-// in one pass (and would repair it), so no format subtlety (end mark, .crs end, stream pieces) lives here.
-constexpr int kSupSubs = 4;
-constexpr int kSupBits = kSupSubs * kSubBits;
-constexpr int kFnStride = 32;  // bytes per landing function: entry s = landing offset in the next super-subsequence
-
-__global__ __launch_bounds__(kDecThreads) void k_sync_table(SyncParams P, uint64_t nsup, uint8_t* __restrict__ tab) {
-  __shared__ DecLds L;
-  const int tid = threadIdx.x;
-  dec_lds_load(L, P.dt, tid, kDecThreads);
-  __syncthreads();
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
-  const uint64_t ngroups = (P.nsub + 63) >> 6;  // 64 subsequences = 16 super-subsequences per wave trip
-  const uint64_t body_bits = P.end_bit - P.body_bit0;
-  uint32_t* in = L.in[wave];
-  for (uint64_t g = (uint64_t)blockIdx.x * kDecWaves + wave; g < ngroups; g += (uint64_t)gridDim.x * kDecWaves) {
+// subsequences per launch).  Deterministic instead: for every subsequence the landing offset of EVERY possible start
+// offset (a code straddles a boundary by less than max_len <= 32 bits) is one small function; where the true decode
+// enters each subsequence is the running composition of those functions -- a parallel scan over function composition
+// (64-ary tree: reduce up, apply down).  The result only seeds start[]: the fixed-point passes then verify it in one
+// pass (and would repair it), so no format subtlety (end mark, end of a .crs, stream pieces) lives here.
+// A function is STRIDE bytes (16 when max_len <= 16, else 32): entry s = landing offset in the next subsequence.
+//
+// k_sync_table: lane = subsequence, its max_len chains three at a time -- three independent shift -> lookup -> add
+// dependency chains per lane hide the LDS round trip that a single chain leaves exposed (four waves per SIMD do not).
+__global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint32_t stride, uint8_t* __restrict__ tab) {
+  GHF_K6_PROLOGUE();
+  const uint32_t S = (uint32_t)max_len < stride ? (uint32_t)max_len : stride;
+  auto run = [&](auto direct_tag) {
+  const int lb = decltype(direct_tag)::value ? -1 : lut_bits;
+  for (uint64_t g = (uint64_t)blockIdx.x * kK6Waves + wave; g < ngroups; g += (uint64_t)gridDim.x * kK6Waves) {
     wave_sync();
-    const uint64_t base = stage_subs(P, g * 64, in, lane);
+    const uint32_t base = k6_stage(P, g * 64, lin, la0, lane);
     wave_sync();
-    const uint64_t sup = g * 16 + (uint64_t)(lane & 15);
-    if (sup >= nsup) continue;
-    const uint64_t limit = body_bits - g * 64 * kSubBits;  // end of the stream, relative to the wave's first subsequence
-    const uint64_t lo = (uint64_t)(lane & 15) * kSupBits, hi = lo + kSupBits;
-    for (uint32_t s = (uint32_t)lane >> 4; s < (uint32_t)max_len; s += 4) {  // four lanes share a super-subsequence
-      uint64_t pos = lo + s;
-      BitReader br;
-      br.init(in, base + pos);
-      while (pos < hi && pos < limit) {
-        uint32_t len;
-        (void)dec_any(L, br.hi(), lut_bits, max_len, len);
-        br.skip(len);
-        pos += len;
+    const uint64_t sub = g * 64 + (uint64_t)lane;
+    if (sub >= P.nsub) continue;
+    const uint32_t limit = k6_limit(body_bits, g);
+    const uint32_t lo = (uint32_t)lane * kSubBits;
+    const uint32_t hi = lo + kSubBits < limit ? lo + kSubBits : limit;  // (behind the stream's end nothing is decoded)
+    uint8_t* const row = tab + sub * stride;
+    for (uint32_t s0 = 0; s0 < S; s0 += 3) {
+      K6Cursor c0, c1, c2;
+      uint32_t p0 = lo + s0, p1 = lo + s0 + 1, p2 = lo + s0 + 2;
+      c0.open(lin, la0, base + p0);
+      c1.open(lin, la0, base + p1);
+      c2.open(lin, la0, base + p2);
+      if (s0 + 1 >= S) p1 = hi;  // no such chain
+      if (s0 + 2 >= S) p2 = hi;
+      while (p0 < hi || p1 < hi || p2 < hi) {
+        if (p0 < hi) p0 += (c0.step(lin, L, T1, lb, max_len) >> 8) & 0xFFu;
+        if (p1 < hi) p1 += (c1.step(lin, L, T1, lb, max_len) >> 8) & 0xFFu;
+        if (p2 < hi) p2 += (c2.step(lin, L, T1, lb, max_len) >> 8) & 0xFFu;
       }
-      tab[sup * kFnStride + s] = pos >= hi ? (uint8_t)(pos - hi) : (uint8_t)0;
+      const uint32_t end = lo + kSubBits;
+      row[s0] = p0 >= end ? (uint8_t)(p0 - end) : (uint8_t)0;
+      if (s0 + 1 < S) row[s0 + 1] = p1 >= end ? (uint8_t)(p1 - end) : (uint8_t)0;
+      if (s0 + 2 < S) row[s0 + 2] = p2 >= end ? (uint8_t)(p2 - end) : (uint8_t)0;
     }
   }
+  };
+  if (direct) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 // one level up: out[t] = f[64 t + 63] o ... o f[64 t]  (entry s: where a decode that enters tile t at offset s leaves it)
-__global__ __launch_bounds__(64) void k_fn_reduce(const uint8_t* __restrict__ f, uint64_t n, uint8_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint8_t fl[64 * kFnStride];
+__global__ __launch_bounds__(64) void k_fn_reduce(const uint8_t* __restrict__ f, uint64_t n, uint32_t stride, uint8_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint8_t fl[64 * 32];
   const uint64_t t = blockIdx.x;
   const int lane = threadIdx.x;
   const uint64_t first = t * 64;
   const int cnt = (int)((n - first < 64) ? (n - first) : 64);
-  for (int i = lane; i < cnt * kFnStride / 16; i += 64)
-    reinterpret_cast<uint4*>(fl)[i] = reinterpret_cast<const uint4*>(f + first * kFnStride)[i];
+  for (int i = lane; i < cnt * (int)stride / 16; i += 64)
+    reinterpret_cast<uint4*>(fl)[i] = reinterpret_cast<const uint4*>(f + first * stride)[i];
   __syncthreads();
-  if (lane < kFnStride) {
+  if (lane < (int)stride) {
     uint32_t cur = (uint32_t)lane;
-    for (int j = 0; j < cnt; ++j) cur = fl[j * kFnStride + (cur & (kFnStride - 1))];
-    out[t * kFnStride + lane] = (uint8_t)cur;
+    for (int j = 0; j < cnt; ++j) cur = fl[j * stride + (cur & (stride - 1))];
+    out[t * stride + lane] = (uint8_t)cur;
   }
 }
 
-// one level down: start[64 t + j] = offset at which the true decode enters element j of tile t, given where it enters the tile
-__global__ __launch_bounds__(64) void k_fn_apply(const uint8_t* __restrict__ f, uint64_t n, const uint8_t* __restrict__ tile_start,
-                                                 uint8_t* __restrict__ start) {
-  __shared__ __attribute__((aligned(16))) uint8_t fl[64 * kFnStride];
+// one level down: start[64 t + j] = offset at which the true decode enters element j of tile t, given where it enters the
+// tile.  The lowest level writes the subsequences' start offsets themselves (16-bit, P.start; [0] keeps the caller's value).
+template <typename OutT>
+__global__ __launch_bounds__(64) void k_fn_apply(const uint8_t* __restrict__ f, uint64_t n, uint32_t stride,
+                                                 const uint8_t* __restrict__ tile_start, OutT* __restrict__ start) {
+  __shared__ __attribute__((aligned(16))) uint8_t fl[64 * 32];
   __shared__ uint8_t st[64];
   const uint64_t t = blockIdx.x;
   const int lane = threadIdx.x;
   const uint64_t first = t * 64;
   const int cnt = (int)((n - first < 64) ? (n - first) : 64);
-  for (int i = lane; i < cnt * kFnStride / 16; i += 64)
-    reinterpret_cast<uint4*>(fl)[i] = reinterpret_cast<const uint4*>(f + first * kFnStride)[i];
+  for (int i = lane; i < cnt * (int)stride / 16; i += 64)
+    reinterpret_cast<uint4*>(fl)[i] = reinterpret_cast<const uint4*>(f + first * stride)[i];
   __syncthreads();
   if (lane == 0) {
     uint32_t cur = tile_start ? tile_start[t] : 0u;
     for (int j = 0; j < cnt; ++j) {
       st[j] = (uint8_t)cur;
-      cur = fl[j * kFnStride + (cur & (kFnStride - 1))];
+      cur = fl[j * stride + (cur & (stride - 1))];
     }
   }
   __syncthreads();
-  if (lane < cnt) start[first + lane] = st[lane];
-}
-
-// seed start[] of the four subsequences of every super-subsequence from the offset at which the true decode enters it
-__global__ __launch_bounds__(kDecThreads) void k_sync_fill(SyncParams P, uint64_t nsup, const uint8_t* __restrict__ sup_start) {
-  __shared__ DecLds L;
-  const int tid = threadIdx.x;
-  dec_lds_load(L, P.dt, tid, kDecThreads);
-  __syncthreads();
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
-  const uint64_t ngroups = (P.nsub + 63) >> 6;
-  const uint64_t body_bits = P.end_bit - P.body_bit0;
-  uint32_t* in = L.in[wave];
-  for (uint64_t g = (uint64_t)blockIdx.x * kDecWaves + wave; g < ngroups; g += (uint64_t)gridDim.x * kDecWaves) {
-    wave_sync();
-    const uint64_t base = stage_subs(P, g * 64, in, lane);
-    wave_sync();
-    const uint64_t sup = g * 16 + (uint64_t)lane;
-    if (lane >= 16 || sup >= nsup) continue;
-    const uint64_t limit = body_bits - g * 64 * kSubBits;
-    const uint64_t lo = (uint64_t)lane * kSupBits, hi = lo + kSupBits;
-    const uint64_t sub0 = sup * kSupSubs;
-    const uint32_t s0 = sup_start[sup];
-    if (sub0 != 0) P.start[sub0] = (uint16_t)s0;  // (subsequence 0 keeps the caller's first_start)
-    uint64_t pos = lo + s0, nb = lo + kSubBits;
-    uint32_t k = 1;
-    BitReader br;
-    br.init(in, base + pos);
-    while (pos < hi && pos < limit && k < (uint32_t)kSupSubs) {
-      uint32_t len;
-      (void)dec_any(L, br.hi(), lut_bits, max_len, len);
-      br.skip(len);
-      pos += len;
-      if (pos >= nb) {  // (a code is shorter than a subsequence: at most one boundary per code)
-        if (sub0 + k < P.nsub) P.start[sub0 + k] = (uint16_t)(pos - nb);
-        ++k;
-        nb += kSubBits;
-      }
-    }
-  }
+  if (lane < cnt && (sizeof(OutT) == 1 || first + lane != 0)) start[first + lane] = (OutT)st[lane];
 }
 
 size_t sync_scan_workspace(uint64_t nsub) {
-  uint64_t n = (nsub + kSupSubs - 1) / kSupSubs, total = 0;
+  uint64_t n = nsub, total = 0;
   for (;;) {
     total += n;
     if (n <= 1) break;
     n = (n + 63) / 64;
   }
-  return (size_t)(total * (kFnStride + 1) + 256 * 16);  // functions + entry offsets of every level, each level 256-aligned
+  return (size_t)(total * (32 + 1) + 256 * 32);  // functions (<= 32 bytes) + entry offsets of every level, each level 256-aligned
 }
 
-void launch_sync_scan(const SyncParams& p, uint8_t* ws, hipStream_t s) {
-  const uint64_t nsup = (p.nsub + kSupSubs - 1) / kSupSubs;
-  if (nsup == 0) return;
-  // carve: functions of level 0.., then entry offsets of level 0..
+static uint32_t k6_blocks(uint64_t nsub) {
+  const uint64_t groups = (nsub + 63) / 64;
+  uint64_t blocks = (groups + kK6Waves - 1) / kK6Waves;
+  if (blocks > 256) blocks = 256;  // one workgroup per CU (LDS)
+  return blocks ? (uint32_t)blocks : 1u;
+}
+
+void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride, hipStream_t s) {
+  if (p.nsub == 0) return;
+  // carve: functions of level 0.., then entry offsets of level 1..
   uint64_t cnt[16];
   uint8_t* fn[16];
   uint8_t* st[16];
   int levels = 0;
   uint8_t* q = ws;
-  for (uint64_t n = nsup;; n = (n + 63) / 64) {
+  for (uint64_t n = p.nsub;; n = (n + 63) / 64) {
     cnt[levels] = n;
     fn[levels] = q;
-    q += (n * kFnStride + 255) & ~(uint64_t)255;
+    q += (n * stride + 255) & ~(uint64_t)255;
     ++levels;
     if (n <= 1 || levels == 16) break;
   }
@@ -1011,19 +991,18 @@ void launch_sync_scan(const SyncParams& p, uint8_t* ws, hipStream_t s) {
     st[l] = q;
     q += (cnt[l] + 255) & ~(uint64_t)255;
   }
-  const uint64_t groups = (p.nsub + 63) / 64;
-  uint64_t blocks = (groups + kDecWaves - 1) / kDecWaves;
-  if (blocks > 256 * 5) blocks = 256 * 5;
-  if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(k_sync_table, dim3((uint32_t)blocks), dim3(kDecThreads), 0, s, p, nsup, fn[0]);
+  hipLaunchKernelGGL(k_sync_table, dim3(k6_blocks(p.nsub)), dim3(kK6Threads), 0, s, p, stride, fn[0]);
   for (int l = 0; l + 1 < levels; ++l)
-    hipLaunchKernelGGL(k_fn_reduce, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], fn[l + 1]);
-  // the top level has one element: the whole body, entered at offset 0 of its first super-subsequence.  (A piece of a stream
-  // whose first code boundary is first_start bits in: that offset is start[0], below max_len by construction.)
-  hipLaunchKernelGGL(k_fn_apply, dim3(1), dim3(64), 0, s, fn[levels - 1], cnt[levels - 1], (const uint8_t*)nullptr, st[levels - 1]);
-  for (int l = levels - 2; l >= 0; --l)
-    hipLaunchKernelGGL(k_fn_apply, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], st[l + 1], st[l]);
-  hipLaunchKernelGGL(k_sync_fill, dim3((uint32_t)blocks), dim3(kDecThreads), 0, s, p, nsup, st[0]);
+    hipLaunchKernelGGL(k_fn_reduce, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], stride, fn[l + 1]);
+  // the top level has one element: the whole body, entered at offset 0 of its first subsequence
+  if (levels == 1) {
+    return;  // a single subsequence: its start is the caller's
+  }
+  hipLaunchKernelGGL(k_fn_apply<uint8_t>, dim3(1), dim3(64), 0, s, fn[levels - 1], cnt[levels - 1], stride, (const uint8_t*)nullptr,
+                     st[levels - 1]);
+  for (int l = levels - 2; l >= 1; --l)
+    hipLaunchKernelGGL(k_fn_apply<uint8_t>, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], stride, st[l + 1], st[l]);
+  hipLaunchKernelGGL(k_fn_apply<uint16_t>, dim3((uint32_t)cnt[1]), dim3(64), 0, s, fn[0], cnt[0], stride, st[1], p.start);
 }
 
 // first subsequence that holds the end mark (valid once the passes have converged)
@@ -1045,52 +1024,56 @@ __global__ __launch_bounds__(256) void k_sync_tile_sums(SyncParams P) {
   if (threadIdx.x == 0) P.tile_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// absolute bit position of every 64th symbol (the side-car's granularity)
-__global__ __launch_bounds__(kDecThreads) void k_sync_index(SyncParams P, uint64_t* __restrict__ seg_abs, uint64_t n_segs, uint64_t n_symbols) {
-  __shared__ DecLds L;
-  __shared__ unsigned long long wsum[kDecWaves];
-  const int tid = threadIdx.x;
-  dec_lds_load(L, P.dt, tid, kDecThreads);
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
+// absolute bit position of every 64th symbol (the side-car's granularity); a workgroup trip = 1024 subsequences = four of
+// the 256-subsequence tiles whose symbol counts k_sync_tile_sums / k_scan prefix-summed
+__global__ __launch_bounds__(kK6Threads, 4) void k_sync_index(SyncParams P, uint64_t* __restrict__ seg_abs, uint64_t n_segs, uint64_t n_symbols) {
+  GHF_K6_PROLOGUE();
+  (void)ngroups;
+  __shared__ unsigned long long wsum[kK6Waves];
   const uint64_t eof_sub = *P.eof_sub;
-  const uint64_t sub = (uint64_t)blockIdx.x * 256 + tid;  // one tile of 256 subsequences per workgroup
-  const bool valid = sub < P.nsub && sub <= eof_sub;
-  const uint32_t c = valid ? P.cnt[sub] : 0u;
-  // exclusive prefix of the symbol counts inside the tile
-  unsigned long long incl = c;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned long long t = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += t;
+  const uint64_t ntrips = (P.nsub + kK6Threads - 1) / kK6Threads;
+  auto run = [&](auto direct_tag) {
+  const int lb = decltype(direct_tag)::value ? -1 : lut_bits;
+  for (uint64_t trip = blockIdx.x; trip < ntrips; trip += gridDim.x) {
+    const uint64_t g = trip * kK6Waves + wave;  // this wave's group of 64 subsequences
+    const uint64_t sub = g * 64 + lane;
+    const bool valid = sub < P.nsub && sub <= eof_sub;
+    const uint32_t c = valid ? P.cnt[sub] : 0u;
+    // exclusive prefix of the symbol counts inside the 256-subsequence tile (4 waves)
+    const uint32_t incl = wave_incl_scan_u32(c);
+    __syncthreads();  // (the previous trip's readers of wsum are done)
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned long long first = incl - c;
+    if (g * 64 < P.nsub) {
+      first += P.tile_sum[g >> 2];  // tile_sum[] holds the exclusive scan by now
+      for (int k = wave & ~3; k < wave; ++k) first += wsum[k];
+    }
+    if (g * 64 >= P.nsub) continue;  // (uniform per wave; the barriers above were passed by everyone)
+    wave_sync();
+    const uint32_t base = k6_stage(P, g * 64, lin, la0, lane);
+    wave_sync();
+    if (!valid) continue;
+    const uint32_t limit = k6_limit(body_bits, g);
+    uint32_t pos = (uint32_t)lane * kSubBits + P.start[sub];
+    K6Cursor cur;
+    cur.open(lin, la0, base + pos);
+    const uint64_t abs0 = P.body_bit0 + g * 64 * kSubBits;  // stream bit of the wave's first subsequence
+    uint32_t mark = (uint32_t)((64u - (uint32_t)(first & 63u)) & 63u);  // my symbols in front of the next segment start
+    uint64_t seg = (first + mark) >> 6;
+    for (uint32_t k = 0; k < c && pos < limit; ++k) {
+      if (k == mark) {
+        if (seg < n_segs) seg_abs[seg] = abs0 + pos;
+        ++seg;
+        mark += 64u;
+      }
+      pos += (cur.step(lin, L, T1, lb, max_len) >> 8) & 0xFFu;
+    }
+    if (c && first + c == n_symbols) seg_abs[n_segs] = abs0 + pos;  // where the last data symbol ends
   }
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads();
-  unsigned long long first = P.tile_sum[blockIdx.x] + incl - c;  // tile_sum[] holds the exclusive scan by now
-  for (int k = 0; k < wave; ++k) first += wsum[k];
-  const uint64_t g = (uint64_t)blockIdx.x * kDecWaves + wave;
-  uint32_t* in = L.in[wave];
-  if (g * 64 >= P.nsub) return;
-  const uint64_t base = stage_subs(P, g * 64, in, lane);
-  wave_sync();
-  if (!valid) return;
-  const uint64_t body_bits = P.end_bit - P.body_bit0;
-  const uint64_t sub_lo = (uint64_t)lane * kSubBits;
-  const uint64_t limit = body_bits - g * 64 * kSubBits;
-  uint64_t pos = sub_lo + P.start[sub];
-  BitReader br;
-  br.init(in, base + pos);
-  const uint64_t abs0 = P.body_bit0 + g * 64 * kSubBits;  // stream bit of the wave's first subsequence
-  for (uint32_t k = 0; k < c && pos < limit; ++k) {
-    const uint64_t sidx = first + k;
-    if ((sidx & 63u) == 0 && (sidx >> 6) < n_segs) seg_abs[sidx >> 6] = abs0 + pos;
-    uint32_t len;
-    (void)dec_any(L, br.hi(), lut_bits, max_len, len);
-    br.skip(len);
-    pos += len;
-  }
-  if (c && first + c == n_symbols) seg_abs[n_segs] = abs0 + pos;  // where the last data symbol ends
+  };
+  if (direct) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 // seg_abs[s] = stream bit of symbol 64 s (s < n_segs), seg_abs[n_segs] = end of the last symbol  ->  the side-car K5 emits:
@@ -1106,11 +1089,7 @@ __global__ __launch_bounds__(256) void k_sync_finalize(const uint64_t* __restric
 }
 
 void launch_sync_pass(const SyncParams& p, hipStream_t s) {
-  const uint64_t groups = (p.nsub + 63) / 64;
-  uint64_t blocks = (groups + kDecWaves - 1) / kDecWaves;
-  if (blocks > 256 * 5) blocks = 256 * 5;
-  if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(k_sync_pass, dim3((uint32_t)blocks), dim3(kDecThreads), 0, s, p);
+  hipLaunchKernelGGL(k_sync_pass, dim3(k6_blocks(p.nsub)), dim3(kK6Threads), 0, s, p);
 }
 void launch_sync_counts(const SyncParams& p, uint64_t* d_total, hipStream_t s) {
   const uint32_t tiles = (uint32_t)((p.nsub + 255) / 256);
@@ -1121,8 +1100,8 @@ void launch_sync_counts(const SyncParams& p, uint64_t* d_total, hipStream_t s) {
 void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_symbols, uint64_t* d_chunk_bit, uint32_t* d_seg_bit,
                        hipStream_t s) {
   const uint64_t n_segs = (n_symbols + kSegSymbols - 1) / kSegSymbols;
-  const uint32_t tiles = (uint32_t)((p.nsub + 255) / 256);
-  hipLaunchKernelGGL(k_sync_index, dim3(tiles), dim3(kDecThreads), 0, s, p, d_seg_abs, n_segs, n_symbols);
+  const uint64_t trips = (p.nsub + kK6Threads - 1) / kK6Threads;
+  hipLaunchKernelGGL(k_sync_index, dim3((uint32_t)(trips < 256 ? (trips ? trips : 1) : 256)), dim3(kK6Threads), 0, s, p, d_seg_abs, n_segs, n_symbols);
   if (n_segs) hipLaunchKernelGGL(k_sync_finalize, dim3((uint32_t)((n_segs + 255) / 256)), dim3(256), 0, s, d_seg_abs, n_segs,
                                  d_chunk_bit, d_seg_bit);
 }

@@ -31,13 +31,9 @@ constexpr int kEmitWaves = kEmitThreads / kWave;
 constexpr int kStageWords = 544;                  // per-wave staging: 128 carry bits + 16384 bits + slack
 constexpr int kStageCapBits = (kStageWords - 8) * 32;
 
-// K7 decode
-constexpr int kDecThreads = 256;
-constexpr int kDecWaves = kDecThreads / kWave;
+// K7 decode / K6 side-car reconstruction
 constexpr int kDecPairBitsMax = 10;
 constexpr int kDecLutBitsMax = 12;
-constexpr int kDecInBytes = 5120;                 // staged compressed span per wave (4096 symbols at <= 10 bits average)
-constexpr int kDecInWords = kDecInBytes / 4;
 
 inline uint32_t chunk_symbols_for(uint64_t n) {
   const uint64_t per_slot = (n + kEmitSlots - 1) / kEmitSlots;
@@ -129,7 +125,7 @@ void launch_sync_pass(const SyncParams& p, hipStream_t s);
 void launch_sync_counts(const SyncParams& p, uint64_t* d_total, hipStream_t s);
 // deterministic seeding of p.start[] (function-composition scan); ws = sync_scan_workspace(p.nsub) bytes, 256-byte aligned
 size_t sync_scan_workspace(uint64_t nsub);
-void launch_sync_scan(const SyncParams& p, uint8_t* ws, hipStream_t s);
+void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride /* 16: max_len <= 16 is known; else 32 */, hipStream_t s);
 void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_symbols, uint64_t* d_chunk_bit, uint32_t* d_seg_bit,
                        hipStream_t s);
 // K1 scratch, all zero between launches: 32 replicas of the 256 totals, the arrival counter (word 8192), 16 ticket
