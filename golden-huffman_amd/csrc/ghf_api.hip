@@ -276,6 +276,50 @@ int ghf_memset_d(ghf_ctx* c, void* d_dst, int value, size_t bytes) {
   return GHF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- events
+struct ghf_event {
+  int device = 0;
+  hipEvent_t ev = nullptr;
+};
+int ghf_event_create(ghf_ctx* c, ghf_event** out) {
+  if (!c || !out) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  ghf_event* e = new (std::nothrow) ghf_event;
+  if (!e) return fail(c, GHF_E_HIP, "out of host memory");
+  e->device = c->device;
+  const hipError_t rc = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+  if (rc != hipSuccess) {
+    delete e;
+    return fail(c, GHF_E_HIP, "hipEventCreateWithFlags", rc);
+  }
+  *out = e;
+  return GHF_OK;
+}
+int ghf_event_destroy(ghf_event* e) {
+  if (!e) return GHF_OK;
+  (void)hipSetDevice(e->device);
+  if (e->ev) (void)hipEventDestroy(e->ev);
+  delete e;
+  return GHF_OK;
+}
+int ghf_event_record(ghf_ctx* c, ghf_event* e) {
+  if (!c || !e) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  GHF_HIP(c, hipEventRecord(e->ev, c->stream));
+  return GHF_OK;
+}
+int ghf_event_wait(ghf_ctx* c, ghf_event* e) {
+  if (!c || !e) return GHF_E_INVAL;
+  GHF_HIP(c, hipSetDevice(c->device));
+  GHF_HIP(c, hipStreamWaitEvent(c->stream, e->ev, 0));
+  return GHF_OK;
+}
+int ghf_event_sync(ghf_event* e) {
+  if (!e) return GHF_E_INVAL;
+  if (hipSetDevice(e->device) != hipSuccess) return GHF_E_HIP;
+  return hipEventSynchronize(e->ev) == hipSuccess ? GHF_OK : GHF_E_HIP;
+}
+
 // ---------------------------------------------------------------------------------------------- encode
 uint32_t ghf_chunk_symbols(size_t n) { return chunk_symbols_for(n); }
 size_t ghf_header_bytes(int max_len) { return 1040 + 8 * (size_t)max_len; }
@@ -288,20 +332,22 @@ size_t ghf_compress_bound(size_t n) {
   return ((b + 15) & ~(size_t)15) + 16;
 }
 
-int ghf_histogram(ghf_ctx* c, const uint8_t* d_in, size_t n, uint64_t* d_hist) {
+static int histogram(ghf_ctx* c, const uint8_t* d_in, size_t n, uint64_t* d_hist, bool add) {
   if (!c || !d_hist || (n && !d_in)) return GHF_E_INVAL;
   GHF_HIP(c, hipSetDevice(c->device));
   const uint32_t cl = chunk_symbols_for(n);
   const size_t nchunks = (size_t)chunk_count_for(n);
   int rc = ensure_ws(c, nchunks);
   if (rc) return rc;
-  launch_histogram(d_in, n, cl, (uint32_t)nchunks, c->d_chunk_hist, d_hist, c->d_hist_acc, c->stream);
+  launch_histogram(d_in, n, cl, (uint32_t)nchunks, c->d_chunk_hist, d_hist, c->d_hist_acc, add, c->stream);
   GHF_HIP(c, hipGetLastError());
-  c->hist_in = d_in;
+  c->hist_in = add ? nullptr : d_in;  // a piece's buffer is refilled before anything is planned: nothing to keep
   c->hist_n = n;
   c->hist_chunk = cl;
   return GHF_OK;
 }
+int ghf_histogram(ghf_ctx* c, const uint8_t* d_in, size_t n, uint64_t* d_hist) { return histogram(c, d_in, n, d_hist, false); }
+int ghf_histogram_add(ghf_ctx* c, const uint8_t* d_in, size_t n, uint64_t* d_hist) { return histogram(c, d_in, n, d_hist, true); }
 
 int ghf_build_code_ex(ghf_ctx* c, const uint64_t* d_hist, ghf_code* d_code, unsigned flags) {
   if (!c || !d_hist || !d_code || (flags & ~(unsigned)GHF_CODE_LIMIT)) return GHF_E_INVAL;
@@ -585,10 +631,10 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
   {
     constexpr int kBatch = 4;
     uint64_t passes = 0;
-    bool scanned = first_start != 0;  // (a stream piece entered mid-code: its first boundary is not a start offset the scan covers)
     const uint32_t fn_stride = (max_len_hint >= 1 && max_len_hint <= 16) ? 16u : 32u;
+    bool scanned = first_start >= fn_stride;  // (the scan follows entry offsets below its stride only)
     if (prefer_scan && !scanned) {
-      launch_sync_scan(p, ws + o_scan, fn_stride, c->stream);
+      launch_sync_scan(p, ws + o_scan, fn_stride, first_start, c->stream);
       scanned = true;
     }
     for (;;) {
@@ -602,7 +648,7 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
       GHF_HIP(c, hipStreamSynchronize(c->stream));
       if ((uint32_t)c->h_u64[5] == 0) break;
       if (!scanned) {
-        launch_sync_scan(p, ws + o_scan, fn_stride, c->stream);
+        launch_sync_scan(p, ws + o_scan, fn_stride, first_start, c->stream);
         scanned = true;
       }
     }
@@ -683,7 +729,14 @@ int ghf_sync_piece(ghf_ctx* c, const uint8_t* d_piece, size_t piece_bytes, uint3
     c->fidx_bytes = piece_bytes;
     return GHF_OK;
   }
-  const int rc = rebuild_index_at(c, d_piece, piece_bytes, 0, end_bit, 2, (size_t)-1, first_bit, landing, has_end_mark);
+  // near-fixed-length codes re-synchronise slowly: the deterministic scan seeds the boundaries at once (as in rebuild_index)
+  GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 6, &d_code->min_len, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  GHF_HIP(c, hipStreamSynchronize(c->stream));
+  int32_t lens[2];
+  std::memcpy(lens, c->h_u64 + 6, sizeof lens);
+  if (lens[1] < 1 || lens[1] > 32 || lens[0] < 1 || lens[0] > lens[1]) return fail(c, GHF_E_FORMAT, "bad min_len / max_len in tables");
+  const int rc = rebuild_index_at(c, d_piece, piece_bytes, 0, end_bit, 2, (size_t)-1, first_bit, landing, has_end_mark,
+                                  /*prefer_scan=*/lens[1] - lens[0] <= 1, lens[1]);
   if (rc) return rc;
   *n_symbols = c->fidx.n_symbols;
   return GHF_OK;

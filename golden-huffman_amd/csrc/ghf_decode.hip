@@ -872,7 +872,7 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
 // pass (and would repair it), so no format subtlety (end mark, end of a .crs, stream pieces) lives here.
 // A function is STRIDE bytes (16 when max_len <= 16, else 32): entry s = landing offset in the next subsequence.
 //
-// k_sync_table: lane = subsequence, its max_len chains three at a time -- three independent shift -> lookup -> add
+// k_sync_table: lane = subsequence, its max_len chains five at a time -- independent shift -> lookup -> add
 // dependency chains per lane hide the LDS round trip that a single chain leaves exposed (four waves per SIMD do not).
 __global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint32_t stride, uint8_t* __restrict__ tab) {
   GHF_K6_PROLOGUE();
@@ -889,23 +889,31 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint
     const uint32_t lo = (uint32_t)lane * kSubBits;
     const uint32_t hi = lo + kSubBits < limit ? lo + kSubBits : limit;  // (behind the stream's end nothing is decoded)
     uint8_t* const row = tab + sub * stride;
-    for (uint32_t s0 = 0; s0 < S; s0 += 3) {
-      K6Cursor c0, c1, c2;
-      uint32_t p0 = lo + s0, p1 = lo + s0 + 1, p2 = lo + s0 + 2;
-      c0.open(lin, la0, base + p0);
-      c1.open(lin, la0, base + p1);
-      c2.open(lin, la0, base + p2);
-      if (s0 + 1 >= S) p1 = hi;  // no such chain
-      if (s0 + 2 >= S) p2 = hi;
-      while (p0 < hi || p1 < hi || p2 < hi) {
-        if (p0 < hi) p0 += (c0.step(lin, L, T1, lb, max_len) >> 8) & 0xFFu;
-        if (p1 < hi) p1 += (c1.step(lin, L, T1, lb, max_len) >> 8) & 0xFFu;
-        if (p2 < hi) p2 += (c2.step(lin, L, T1, lb, max_len) >> 8) & 0xFFu;
+    constexpr uint32_t NC = 5;  // chains in flight per lane
+    for (uint32_t s0 = 0; s0 < S; s0 += NC) {
+      K6Cursor c[NC];
+      uint32_t p[NC];
+#pragma unroll
+      for (uint32_t j = 0; j < NC; ++j) {
+        p[j] = lo + s0 + j;
+        c[j].open(lin, la0, base + p[j]);
+        if (s0 + j >= S) p[j] = hi;  // no such chain
+      }
+      for (;;) {
+        bool any = false;
+#pragma unroll
+        for (uint32_t j = 0; j < NC; ++j) {
+          if (p[j] < hi) {
+            p[j] += (c[j].step(lin, L, T1, lb, max_len) >> 8) & 0xFFu;
+            any = true;
+          }
+        }
+        if (!any) break;
       }
       const uint32_t end = lo + kSubBits;
-      row[s0] = p0 >= end ? (uint8_t)(p0 - end) : (uint8_t)0;
-      if (s0 + 1 < S) row[s0 + 1] = p1 >= end ? (uint8_t)(p1 - end) : (uint8_t)0;
-      if (s0 + 2 < S) row[s0 + 2] = p2 >= end ? (uint8_t)(p2 - end) : (uint8_t)0;
+#pragma unroll
+      for (uint32_t j = 0; j < NC; ++j)
+        if (s0 + j < S) row[s0 + j] = p[j] >= end ? (uint8_t)(p[j] - end) : (uint8_t)0;
     }
   }
   };
@@ -934,7 +942,7 @@ __global__ __launch_bounds__(64) void k_fn_reduce(const uint8_t* __restrict__ f,
 // tile.  The lowest level writes the subsequences' start offsets themselves (16-bit, P.start; [0] keeps the caller's value).
 template <typename OutT>
 __global__ __launch_bounds__(64) void k_fn_apply(const uint8_t* __restrict__ f, uint64_t n, uint32_t stride,
-                                                 const uint8_t* __restrict__ tile_start, OutT* __restrict__ start) {
+                                                 const uint8_t* __restrict__ tile_start, uint32_t entry, OutT* __restrict__ start) {
   __shared__ __attribute__((aligned(16))) uint8_t fl[64 * 32];
   __shared__ uint8_t st[64];
   const uint64_t t = blockIdx.x;
@@ -945,7 +953,7 @@ __global__ __launch_bounds__(64) void k_fn_apply(const uint8_t* __restrict__ f, 
     reinterpret_cast<uint4*>(fl)[i] = reinterpret_cast<const uint4*>(f + first * stride)[i];
   __syncthreads();
   if (lane == 0) {
-    uint32_t cur = tile_start ? tile_start[t] : 0u;
+    uint32_t cur = tile_start ? tile_start[t] : entry;  // top level: where the caller says the first code begins
     for (int j = 0; j < cnt; ++j) {
       st[j] = (uint8_t)cur;
       cur = fl[j * stride + (cur & (stride - 1))];
@@ -972,7 +980,7 @@ static uint32_t k6_blocks(uint64_t nsub) {
   return blocks ? (uint32_t)blocks : 1u;
 }
 
-void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride, hipStream_t s) {
+void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride, uint32_t entry, hipStream_t s) {
   if (p.nsub == 0) return;
   // carve: functions of level 0.., then entry offsets of level 1..
   uint64_t cnt[16];
@@ -994,15 +1002,15 @@ void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride, hipStre
   hipLaunchKernelGGL(k_sync_table, dim3(k6_blocks(p.nsub)), dim3(kK6Threads), 0, s, p, stride, fn[0]);
   for (int l = 0; l + 1 < levels; ++l)
     hipLaunchKernelGGL(k_fn_reduce, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], stride, fn[l + 1]);
-  // the top level has one element: the whole body, entered at offset 0 of its first subsequence
+  // the top level has one element: the whole body, entered at bit `entry` (< stride) of its first subsequence
   if (levels == 1) {
     return;  // a single subsequence: its start is the caller's
   }
   hipLaunchKernelGGL(k_fn_apply<uint8_t>, dim3(1), dim3(64), 0, s, fn[levels - 1], cnt[levels - 1], stride, (const uint8_t*)nullptr,
-                     st[levels - 1]);
+                     entry, st[levels - 1]);
   for (int l = levels - 2; l >= 1; --l)
-    hipLaunchKernelGGL(k_fn_apply<uint8_t>, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], stride, st[l + 1], st[l]);
-  hipLaunchKernelGGL(k_fn_apply<uint16_t>, dim3((uint32_t)cnt[1]), dim3(64), 0, s, fn[0], cnt[0], stride, st[1], p.start);
+    hipLaunchKernelGGL(k_fn_apply<uint8_t>, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], stride, st[l + 1], 0u, st[l]);
+  hipLaunchKernelGGL(k_fn_apply<uint16_t>, dim3((uint32_t)cnt[1]), dim3(64), 0, s, fn[0], cnt[0], stride, st[1], 0u, p.start);
 }
 
 // first subsequence that holds the end mark (valid once the passes have converged)

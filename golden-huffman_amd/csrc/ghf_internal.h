@@ -125,14 +125,15 @@ void launch_sync_pass(const SyncParams& p, hipStream_t s);
 void launch_sync_counts(const SyncParams& p, uint64_t* d_total, hipStream_t s);
 // deterministic seeding of p.start[] (function-composition scan); ws = sync_scan_workspace(p.nsub) bytes, 256-byte aligned
 size_t sync_scan_workspace(uint64_t nsub);
-void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride /* 16: max_len <= 16 is known; else 32 */, hipStream_t s);
+void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride /* 16: max_len <= 16 is known; else 32 */,
+                      uint32_t entry /* bit at which the first code begins, < stride */, hipStream_t s);
 void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_symbols, uint64_t* d_chunk_bit, uint32_t* d_seg_bit,
                        hipStream_t s);
 // K1 scratch, all zero between launches: 32 replicas of the 256 totals, the arrival counter (word 8192), 16 ticket
 // counters (word 8208 + 16 k, one 128-byte line each)
 constexpr size_t kHistAccWords = 32 * 256 + 16 + 16 * 16;
 void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk, uint32_t nchunks, uint32_t* d_chunk_hist,
-                      uint64_t* d_hist, uint64_t* d_acc, hipStream_t s);
+                      uint64_t* d_hist, uint64_t* d_acc, bool add, hipStream_t s);
 void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, uint32_t flags, hipStream_t s);
 void launch_write_header(const ghf_code* d_code, uint8_t* d_out, uint64_t cap, int* d_status, hipStream_t s);
 void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk, uint32_t nchunks, const uint32_t* d_chunk_hist,

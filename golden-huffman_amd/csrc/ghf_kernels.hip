@@ -34,7 +34,8 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
                                                             uint32_t chunk32, uint32_t nchunks,
                                                             uint32_t* __restrict__ chunk_hist,
                                                             unsigned long long* __restrict__ hist,
-                                                            unsigned long long* __restrict__ acc /* [32][256] + done */) {
+                                                            unsigned long long* __restrict__ acc /* [32][256] + done */,
+                                                            uint32_t add /* hist += instead of hist = */) {
   static_assert(kHistRep == 32, "replica index is lane % 32");
   __shared__ uint32_t lh[256 * kHistRep];
   __shared__ bool s_last;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
       sum += __hip_atomic_load(&acc[r * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&acc[r * 256 + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    hist[tid] = sum;
+    hist[tid] = add ? hist[tid] + sum : sum;
     if (tid < 16) __hip_atomic_store(&acc[32 * 256 + 16 + tid * 16], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) {
       hist[256] = 1;  // include/encoder.h:128 end-of-stream mark counts once
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
 }
 
 void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk, uint32_t nchunks, uint32_t* d_chunk_hist,
-                      uint64_t* d_hist, uint64_t* d_acc, hipStream_t s) {
+                      uint64_t* d_hist, uint64_t* d_acc, bool add, hipStream_t s) {
   // one resident round of workgroups, 4 per CU: measured faster than the 5 the LDS would allow (2 GiB stream:
   // 5.55 TB/s at 1024 workgroups vs 4.95 TB/s at 1280 -- the fifth workgroup only adds L2/LDS pressure)
   static int ncu = 0;
@@ -175,7 +176,8 @@ void launch_histogram(const uint8_t* d_in, uint64_t n, uint32_t chunk, uint32_t 
   if (grid > nchunks) grid = nchunks;
   if (grid == 0) grid = 1;
   hipLaunchKernelGGL(k_histogram, dim3(grid), dim3(kHistThreads), 0, s, d_in, n, chunk, nchunks, d_chunk_hist,
-                     reinterpret_cast<unsigned long long*>(d_hist), reinterpret_cast<unsigned long long*>(d_acc));
+                     reinterpret_cast<unsigned long long*>(d_hist), reinterpret_cast<unsigned long long*>(d_acc),
+                     add ? 1u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------

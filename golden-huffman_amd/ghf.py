@@ -103,6 +103,7 @@ EXPORTS = [
     "ghf_crs_decode", "ghf_crs_decoded_size", "ghf_build_code_ex", "ghf_compress_ex", "ghf_sync_piece", "ghf_decode_prepare",
     "ghf_comm_unique_id", "ghf_comm_init_rank", "ghf_comm_destroy", "ghf_comm_world", "ghf_rccl_version",
     "ghf_comm_allreduce_hist", "ghf_comm_allgather_total", "ghf_encode_sharded", "ghf_shard_bound",
+    "ghf_event_create", "ghf_event_destroy", "ghf_event_record", "ghf_event_wait", "ghf_event_sync", "ghf_histogram_add",
 ]
 COMM_ID_BYTES = 128
 
@@ -143,6 +144,12 @@ def lib():
     L.ghf_copy_d2h.argtypes = [vp, vp, vp, sz]
     L.ghf_memset_d.argtypes = [vp, vp, i32, sz]
     L.ghf_histogram.argtypes = [vp, vp, sz, vp]
+    L.ghf_histogram_add.argtypes = [vp, vp, sz, vp]
+    L.ghf_event_create.argtypes = [vp, C.POINTER(vp)]
+    for f in (L.ghf_event_destroy, L.ghf_event_sync):
+        f.argtypes = [vp]
+    for f in (L.ghf_event_record, L.ghf_event_wait):
+        f.argtypes = [vp, vp]
     L.ghf_build_code.argtypes = [vp, vp, vp]
     L.ghf_write_header.argtypes = [vp, vp, vp, sz]
     L.ghf_header_bytes.argtypes = [i32]
@@ -321,6 +328,12 @@ class Context:
         n = d_in.numel() if n is None else n
         hist = self.torch.empty(NSYM, dtype=self.torch.int64, device=self.device) if out is None else out
         self._chk(self.L.ghf_histogram(self.h, d_in.data_ptr(), n, hist.data_ptr()), "ghf_histogram")
+        return hist
+
+    def histogram_add(self, d_in, hist, n=None):
+        """hist[0..255] += counts of d_in (an input that arrives in pieces); hist[256] = 1"""
+        n = d_in.numel() if n is None else n
+        self._chk(self.L.ghf_histogram_add(self.h, d_in.data_ptr(), n, hist.data_ptr()), "ghf_histogram_add")
         return hist
 
     def build_code(self, d_hist, d_code=None, flags=0):

@@ -9,6 +9,9 @@
 //   ghf_tool <file> 2         decompress <file> -> <file>.de    (normal Huffman, :299-301)
 //   ghf_tool <file> 3         compress   <file> -> <file>.crs2                 (unit_tests/test.cc:302-304)
 //   ghf_tool <file> 4|5|6     decompress <file> -> <file>.de   (canonical | fast | table decoder, :306-314)
+//   ghf_tool <file> 7         file-to-file throughput of the canonical pair: compress and decompress
+//                             <file> three times each, byte-compare, print one JSON line (input bytes / wall time;
+//                             the first run includes context creation, pinned rings and the I/O threads)
 // Exit code 0 = everything matched.
 #include <chrono>
 #include <cstdio>
@@ -97,11 +100,42 @@ static bool run(const char* name, F f) {
   return ok;
 }
 
+static int file_to_file_perf() {
+  FILE* f = fopen(infile_name.c_str(), "rb");
+  if (!f) {
+    fprintf(stderr, "cannot open %s\n", infile_name.c_str());
+    return 1;
+  }
+  fseek(f, 0, SEEK_END);
+  const double gb = (double)ftell(f) / 1e9;
+  fclose(f);
+  double c_ms[3], d_ms[3];
+  for (int i = 0; i < 3; ++i) {
+    // fresh output files each time: truncating a multi-GiB file in /dev/shm costs as much as writing a third of it
+    remove((infile_name + ".crs2").c_str());
+    remove((infile_name + ".crs2.de").c_str());
+    double t0 = now_ms();
+    canonical_huff_char_compress(infile_name);
+    c_ms[i] = now_ms() - t0;
+    t0 = now_ms();
+    decompress_with<HipCanonicalHuffDecoder<> >(outfile_name);
+    d_ms[i] = now_ms() - t0;
+  }
+  const bool ok = compressor_func_test();
+  const double c = c_ms[1] < c_ms[2] ? c_ms[1] : c_ms[2], d = d_ms[1] < d_ms[2] ? d_ms[1] : d_ms[2];
+  printf("{\"file_GB\": %.6f, \"compress_ms\": [%.2f, %.2f, %.2f], \"decompress_ms\": [%.2f, %.2f, %.2f], "
+         "\"compress_GBps\": %.3f, \"decompress_GBps\": %.3f, \"first_run_compress_GBps\": %.3f, \"round_trip_ok\": %s}\n",
+         gb, c_ms[0], c_ms[1], c_ms[2], d_ms[0], d_ms[1], d_ms[2], gb / (c * 1e-3), gb / (d * 1e-3), gb / (c_ms[0] * 1e-3),
+         ok ? "true" : "false");
+  return ok ? 0 : 1;
+}
+
 int main(int argc, char* argv[]) {
   if (argc >= 2) infile_name = argv[1];
   try {
     if (argc == 3) {
       const int type = atoi(argv[2]);
+      if (type == 7) return file_to_file_perf();
       if (type == 1) normal_huff_char_compress(infile_name);
       else if (type == 2) decompress_with<HipNormalHuffDecoder<> >(infile_name);
       else if (type == 3) canonical_huff_char_compress(infile_name);
@@ -109,7 +143,7 @@ int main(int argc, char* argv[]) {
       else if (type == 5) decompress_with<HipFastCanonicalHuffDecoder<> >(infile_name);
       else if (type == 6) decompress_with<HipTableCanonicalHuffDecoder<> >(infile_name);
       else {
-        fprintf(stderr, "mode must be 1..6\n");
+        fprintf(stderr, "mode must be 1..7\n");
         return 2;
       }
       return 0;

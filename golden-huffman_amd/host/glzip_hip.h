@@ -14,8 +14,9 @@
 // Differences, all on the side of doing MORE than the reference:
 //   * failures (unopenable file, empty input, code > 32 bits, corrupt stream, HIP error) throw
 //     glzip_hip::Error; the reference has no error path at all (include/encoder.h:67-70 FIXME);
-//   * file I/O goes through one pinned host buffer and hipMemcpyAsync instead of 64 KiB stdio buffers
-//     (utils/include/buffer.h:61-317);
+//   * file I/O is a pipeline of pieces (detail::Pipe below: reader/writer threads, pinned rings, one stream per
+//     direction) instead of 64 KiB stdio buffers (utils/include/buffer.h:61-317); like the reference, the encoder
+//     reads its input twice when the file does not fit its residency budget, and device memory is O(piece);
 //   * only the byte-keyed (unsigned char) instantiation exists; anything else is a compile error.
 // No HIP header is needed to compile this file: it links against libghf.so only.
 #ifndef GLZIP_HIP_H_
@@ -23,8 +24,23 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <math.h>
+#include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <functional>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <atomic>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ghf.h"
@@ -63,6 +79,7 @@ class Session {
       throw Error(rc, std::string(where) + ": " + ghf_status_string(rc));
     }
   }
+  bool live() const { return ctx_ != NULL; }
   static int device_from_env() {
     const char* e = getenv("GHF_DEVICE");
     return e ? atoi(e) : 0;
@@ -172,6 +189,505 @@ class Stager {
   PinnedBuf h_[2];
 };
 
+
+// ------------------------------------------------------------------------------------------------ the file pipeline
+// what replaces utils/include/buffer.h:61-317 for the canonical policies.  A file moves in pieces:
+//   reader threads (pread -> pinned ring) -> copy-in stream -> kernel stream -> copy-out stream -> pinned ring ->
+//   writer threads (pwrite at the piece's own file offset)
+// Three contexts = three HIP streams, ordered by events (ghf_event_*), so the H2D of piece k+1, the kernels of piece k
+// and the D2H of piece k-1 run at the same time and the host never waits for a stream as a whole.
+inline size_t env_bytes(const char* name, size_t dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  char* end = NULL;
+  unsigned long long v = strtoull(e, &end, 10);
+  if (end && (*end == 'k' || *end == 'K')) v <<= 10;
+  else if (end && (*end == 'm' || *end == 'M')) v <<= 20;
+  else if (end && (*end == 'g' || *end == 'G')) v <<= 30;
+  return (size_t)v;
+}
+
+// GHF_PIPE_TRACE=1: wall time of every step of the policies, on stderr
+class StepTimer {
+ public:
+  explicit StepTimer(const char* what) : what_(what), on_(getenv("GHF_PIPE_TRACE") != NULL), t0_(now()) {}
+  ~StepTimer() {
+    if (on_) fprintf(stderr, "[ghf] %-20s %9.2f ms\n", what_, now() - t0_);
+  }
+  static double now() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+
+ private:
+  const char* what_;
+  bool on_;
+  double t0_;
+};
+
+class StepSum {  // GHF_PIPE_TRACE=1: time spent inside one kind of call, summed over an operation
+ public:
+  explicit StepSum(const char* what) : what_(what), on_(getenv("GHF_PIPE_TRACE") != NULL), ms_(0), n_(0) {}
+  ~StepSum() { report(); }
+  void report() {
+    if (on_ && n_) fprintf(stderr, "[ghf]   %-18s %9.2f ms in %zu calls\n", what_, ms_, n_);
+    ms_ = 0, n_ = 0;
+  }
+  struct Scope {
+    StepSum& s;
+    double t0;
+    explicit Scope(StepSum& ss) : s(ss), t0(ss.on_ ? StepTimer::now() : 0) {}
+    ~Scope() {
+      if (s.on_) s.ms_ += StepTimer::now() - t0, ++s.n_;
+    }
+  };
+
+ private:
+  const char* what_;
+  bool on_;
+  double ms_;
+  size_t n_;
+};
+
+class Event {
+ public:
+  Event() : e_(NULL), live_(false) {}
+  ~Event() {
+    if (e_) ghf_event_destroy(e_);
+  }
+  void record(const Session& s) {
+    if (!e_) s.check(ghf_event_create(s.ctx(), &e_), "ghf_event_create");
+    s.check(ghf_event_record(s.ctx(), e_), "ghf_event_record");
+    live_ = true;
+  }
+  void hold(const Session& s) const {  // s's stream waits; the host does not
+    if (live_) s.check(ghf_event_wait(s.ctx(), e_), "ghf_event_wait");
+  }
+  void sync() const {  // the host waits
+    if (live_ && ghf_event_sync(e_) != GHF_OK) throw Error(GHF_E_HIP, "ghf_event_sync");
+  }
+
+ private:
+  Event(const Event&);
+  Event& operator=(const Event&);
+  ghf_event* e_;
+  bool live_;
+};
+
+class IoPool {  // the reader/writer threads; a job's exception comes back through its future
+ public:
+  IoPool() : stop_(false) {}
+  ~IoPool() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (size_t i = 0; i < th_.size(); ++i) th_[i].join();
+  }
+  std::future<void> submit(std::function<void()> f) {
+    if (th_.empty()) {
+      size_t n = env_bytes("GHF_IO_THREADS", 12);
+      if (n < 1) n = 1;
+      if (n > 64) n = 64;
+      for (size_t i = 0; i < n; ++i) th_.push_back(std::thread(&IoPool::loop, this));
+    }
+    std::packaged_task<void()> t(std::move(f));
+    std::future<void> fut = t.get_future();
+    {
+      std::lock_guard<std::mutex> g(m_);
+      q_.push_back(std::move(t));
+    }
+    cv_.notify_one();
+    return fut;
+  }
+
+ private:
+  void loop() {
+    for (;;) {
+      std::packaged_task<void()> t;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return stop_ || !q_.empty(); });
+        if (q_.empty()) return;
+        t = std::move(q_.front());
+        q_.pop_front();
+      }
+      t();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<std::packaged_task<void()> > q_;
+  std::vector<std::thread> th_;
+  bool stop_;
+};
+
+inline void pread_all(int fd, uint8_t* dst, size_t len, size_t off) {
+  while (len) {
+    const ssize_t r = pread(fd, dst, len, (off_t)off);
+    if (r <= 0) throw Error(GHF_E_INVAL, "short read");
+    dst += r, off += (size_t)r, len -= (size_t)r;
+  }
+}
+inline void pwrite_all(int fd, const uint8_t* src, size_t len, size_t off) {
+  while (len) {
+    const ssize_t r = pwrite(fd, src, len, (off_t)off);
+    if (r <= 0) throw Error(GHF_E_INVAL, "short write");
+    src += r, off += (size_t)r, len -= (size_t)r;
+  }
+}
+
+struct Jobs {  // the pool jobs that still use a pinned buffer
+  std::vector<std::future<void> > f;
+  void add(std::future<void> x) { f.push_back(std::move(x)); }
+  void wait() {
+    for (size_t i = 0; i < f.size(); ++i)
+      if (f[i].valid()) f[i].wait();
+  }
+  void drop() {
+    wait();
+    f.clear();
+  }
+  void get() {  // wait; the first error, if any, is rethrown
+    std::vector<std::future<void> > t;
+    t.swap(f);
+    std::exception_ptr err;
+    for (size_t i = 0; i < t.size(); ++i) {
+      try {
+        t[i].get();
+      } catch (...) {
+        if (!err) err = std::current_exception();
+      }
+    }
+    if (err) std::rethrow_exception(err);
+  }
+};
+
+class Pipe {
+ public:
+  static const int kSlots = 6;  // per ring; a ring is used first-in first-out
+  static const size_t kLag = 2;
+  static const size_t kFill = (size_t)4 << 20;        // bytes per copy job
+  static const size_t kAllocStep = (size_t)256 << 20;  // bytes per fallocate
+  static const size_t kUnmapStep = (size_t)64 << 20;   // bytes per munmap behind the copies
+  Pipe() : t_read_("wait for a read"), t_slot_("wait for a slot"), t_land_("wait for a D2H"), t_alloc_("fallocate"), t_flush_("last writes"),
+           piece_(0), in_next_(0), out_next_(0), sink_fd_(-1), sink_len_(0), ready_(0), map_(NULL), sized_(false), no_alloc_(false) {}
+  ~Pipe() { quiesce(); }
+  // One pipe (three contexts, the pinned rings, the I/O threads) per host thread, shared by the policy objects that
+  // are alive on it and gone with the last of them: a Decompressor made after a Compressor (unit_tests/test.cc:136-156
+  // makes a new one per call) starts warm.
+  static std::shared_ptr<Pipe> shared() {
+    static thread_local std::weak_ptr<Pipe> w;
+    std::shared_ptr<Pipe> p = w.lock();
+    if (!p) {
+      p.reset(new Pipe);
+      w = p;
+    }
+    return p;
+  }
+
+  // piece size: GHF_PIECE_BYTES (default 16 MiB; a multiple of 64 KiB so that pieces stay 16-byte aligned in the stream)
+  size_t piece() {
+    if (!piece_) {
+      size_t p = env_bytes("GHF_PIECE_BYTES", (size_t)16 << 20);
+      p = (p + 0xFFFF) & ~(size_t)0xFFFF;
+      piece_ = p ? p : 0x10000;
+    }
+    return piece_;
+  }
+  const Session& in() const { return in_s_; }    // copy-in stream
+  const Session& run() const { return run_s_; }  // kernel stream
+  const Session& out() const { return out_s_; }  // copy-out stream
+  size_t piece_bytes() const { return piece_; }
+
+  // start of an operation: whatever an earlier one that failed half-way left behind is dropped, not written
+  void begin() {
+    for (int ring = 0; ring < 2; ++ring) {
+      Ring& r = ring ? out_ring_ : in_ring_;
+      for (size_t i = 0; i < r.size(); ++i) r[i].job.drop();
+    }
+    pend_.clear();
+    landing_.clear();
+    unmap_.drop();
+    if (map_) munmap(map_ + unmapped_, sink_len_ - unmapped_);
+    map_ = NULL;
+    sink_fd_ = -1;
+  }
+
+  // ---- file -> device -------------------------------------------------------------------------------------------
+  // The byte range [base, base + total) of fd in pieces of piece() bytes, each followed by `extra` look-ahead bytes of
+  // the next piece, the whole zero-filled up to padded(k).  Reads run `kSlots - 2` pieces ahead on the pool.
+  void open_feed(int fd, size_t base, size_t total, size_t extra) {
+    fd_ = fd, base_ = base, total_ = total, extra_ = extra;
+    next_read_ = next_feed_ = 0;
+    pend_.clear();
+    ensure_ring(in_ring_, piece() + 64);
+  }
+  size_t pieces() const { return (total_ + piece_ - 1) / piece_; }
+  size_t own(size_t k) const { return total_ - k * piece_ < piece_ ? total_ - k * piece_ : piece_; }
+  size_t padded(size_t k) const { return extra_ ? ((own(k) + extra_ + 15) & ~(size_t)15) + 16 : own(k); }
+  // the next piece (in order) goes to d_dst on the copy-in stream; `arrived` is recorded behind the copy
+  void feed(uint8_t* d_dst, Event& arrived) {
+    const size_t k = next_feed_++;
+    prefetch(k + kSlots - 2);
+    Slot& sl = in_ring_[pend_.front()];
+    pend_.pop_front();
+    {
+      StepSum::Scope t(t_read_);
+      sl.job.get();  // the read is done (or rethrows its error)
+    }
+    in_s_.check(ghf_copy_h2d(in_s_.ctx(), d_dst, sl.buf.p, padded(k)), "ghf_copy_h2d");
+    sl.copied.record(in_s_);
+    arrived.record(in_s_);
+    prefetch(k + kSlots - 1);  // the slot of piece k-1 is free by now (its copy went out one feed ago)
+  }
+
+  // ---- device -> file -------------------------------------------------------------------------------------------
+  // After `ready`: d_src[0, bytes) goes to fd at file_off -- D2H on the copy-out stream in segments of piece() bytes,
+  // each written by the pool once it has landed.  Returns when every copy is enqueued; at most kLag + 1 landed or
+  // landing segments wait for their write at any time, the oldest is handed to the pool before a new slot is taken.
+  void drain(const Event& ready, const uint8_t* d_src, size_t bytes, int fd, size_t file_off) {
+    ensure_ring(out_ring_, piece());
+    ready.hold(out_s_);
+    for (size_t off = 0; off < bytes; off += piece_) {
+      while (landing_.size() > kLag) store_oldest();
+      Landing l;
+      l.slot = acquire(out_ring_, out_next_);
+      l.len = bytes - off < piece_ ? bytes - off : piece_;
+      l.fd = fd;
+      l.at = file_off + off;
+      Slot& sl = out_ring_[l.slot];
+      out_s_.check(ghf_copy_d2h(out_s_.ctx(), sl.buf.p, d_src + off, l.len), "ghf_copy_d2h");
+      sl.copied.record(out_s_);
+      landing_.push_back(l);
+    }
+  }
+  // every write that was started has reached the file (write errors surface here)
+  void flush() {
+    while (!landing_.empty()) store_oldest();
+    for (size_t i = 0; i < out_ring_.size(); ++i) out_ring_[i].job.get();
+  }
+
+  // ---- the output file ------------------------------------------------------------------------------------------
+  // A new file in /dev/shm takes 8.4 GB/s from ONE pwrite-ing thread and less from several (they queue on the inode
+  // lock and on the page allocation); pages that fallocate made (20 GB/s, one call) take 54 GB/s from 8 threads that
+  // MADV_POPULATE_WRITE + memcpy through a shared mapping -- as long as nobody allocates at the same time
+  // (profiles/r02_io/: io_bench*.log).  So: drain() targets inside the sink go through the mapping; pages are made in
+  // steps of kAllocStep by the thread that drives the pipeline, between two rounds of copies.  `bound` >= the final
+  // size; close_sink(final) cuts the file to it.  GHF_SINK=pwrite keeps everything on pwrite (and so does any failure
+  // of ftruncate / mmap / fallocate: a full file system is then an error code, not a SIGBUS).
+  // `exact`: bound IS the final size (all of its pages are made right away, in one call).
+  void open_sink(int fd, size_t bound, bool exact) {
+    sink_fd_ = fd;
+    sink_len_ = bound;
+    ready_ = 0;
+    sized_ = no_alloc_ = false;
+    pre_job_.wait();
+    const size_t made = pre_fd_ == fd ? pre_done_.load() : 0;
+    pre_fd_ = -1;
+    if (!wants_map(bound)) return;
+    if (ftruncate(fd, (off_t)bound) != 0) return;
+    sized_ = true;
+    void* m = mmap(NULL, bound, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (m == MAP_FAILED) return;
+    map_ = static_cast<uint8_t*>(m);
+    unmapped_ = 0;
+    const size_t end = (bound + 4095) & ~(size_t)4095;
+    ready_ = made < end ? made : end;
+    if (exact) (void)reserve(bound, true);
+  }
+  // Pages for [0, bytes) of the file that open_sink() is given next, made by a pool thread from now on: the encoder
+  // knows roughly how much it will write long before it may write (the two passes of a Huffman coder),
+  // and page-making is the slowest stage of the output side.  cancel_presize() before the file is closed.
+  void presize(int fd, size_t bytes) {
+    cancel_presize();
+    if (!wants_map(bytes)) return;
+    pre_fd_ = fd;
+    pre_done_ = 0;
+    pre_stop_ = false;
+    std::atomic<size_t>* done = &pre_done_;
+    std::atomic<bool>* stop = &pre_stop_;
+    pre_job_.add(pool_.submit([fd, bytes, done, stop] {
+      const size_t end = (bytes + 4095) & ~(size_t)4095;
+      for (size_t o = 0; o < end && !stop->load(); o += kAllocStep) {
+        const size_t len = end - o < kAllocStep ? end - o : kAllocStep;
+        if (fallocate(fd, 0, (off_t)o, (off_t)len) != 0) break;
+        done->store(o + len);
+      }
+    }));
+  }
+  // presize() was started after open_sink(): count what it made (call cancel_presize() first)
+  void adopt_presized(int fd) {
+    if (pre_fd_last_ == fd && map_ && pre_done_.load() > ready_) {
+      const size_t end = (sink_len_ + 4095) & ~(size_t)4095;
+      ready_ = pre_done_.load() < end ? pre_done_.load() : end;
+    }
+  }
+  void cancel_presize() {
+    pre_fd_last_ = pre_fd_;
+    pre_stop_ = true;
+    pre_job_.drop();
+    pre_fd_ = -1;
+  }
+  static bool wants_map(size_t bound) {
+    const char* how = getenv("GHF_SINK");
+    return how ? strcmp(how, "mmap") == 0 : bound >= ((size_t)8 << 20);
+  }
+  // the driver knows the final size by now (the decoder, once everything is decoded): make the rest of the pages at once
+  void reserve_all(size_t bytes) { (void)reserve(bytes, true); }
+  // an operation failed half-way: nothing more is written, the mapping goes, the file is emptied
+  void abandon_sink() {
+    for (size_t i = 0; i < out_ring_.size(); ++i) out_ring_[i].job.drop();
+    landing_.clear();
+    unmap_.drop();
+    if (map_) munmap(map_ + unmapped_, sink_len_ - unmapped_);
+    map_ = NULL;
+    if (sized_ && sink_fd_ >= 0) (void)!ftruncate(sink_fd_, 0);
+    sized_ = false;
+    sink_fd_ = -1;
+  }
+  void close_sink(size_t final_size) {
+    {
+      StepSum::Scope t(t_flush_);
+      flush();
+    }
+    t_read_.report(), t_slot_.report(), t_land_.report(), t_alloc_.report(), t_flush_.report();
+    if (sized_ && ftruncate(sink_fd_, (off_t)final_size) != 0) throw Error(GHF_E_INVAL, "ftruncate");
+    if (map_) munmap(map_ + unmapped_, sink_len_ - unmapped_);  // what the pool has not taken down yet (the last few segments)
+    unmap_.drop();
+    map_ = NULL;
+    sink_fd_ = -1;
+  }
+
+ private:
+  struct Slot {
+    PinnedBuf buf;
+    Event copied;           // the last hipMemcpyAsync that used buf
+    Jobs job;               // the last read into / writes from buf
+  };
+  typedef std::vector<Slot> Ring;
+  void ensure_ring(Ring& r, size_t bytes) {
+    if (r.empty()) r = Ring(kSlots);
+    for (size_t i = 0; i < r.size(); ++i)
+      if (r[i].buf.n < bytes) r[i].buf.alloc(run_s_, bytes);
+  }
+  int acquire(Ring& r, size_t& next) {  // oldest slot of the ring, once its last job and copy are over
+    StepSum::Scope t(t_slot_);
+    const int si = (int)(next++ % r.size());
+    r[si].job.get();
+    r[si].copied.sync();
+    return si;
+  }
+  struct Landing {  // a segment on its way from the device into the pinned ring
+    int slot, fd;
+    size_t len, at;
+  };
+  void store_oldest() {
+    const Landing l = landing_.front();
+    landing_.pop_front();
+    Slot& sl = out_ring_[l.slot];
+    {
+      StepSum::Scope t(t_land_);
+      sl.copied.sync();
+    }
+    const uint8_t* src = sl.buf.u8();
+    const int fd = l.fd;
+    const size_t len = l.len, at = l.at;
+    if (fd == sink_fd_ && reserve(at + len)) {
+      uint8_t* map = map_;
+      for (size_t o = 0; o < len; o += kFill) {  // several threads per segment: the slot is free again sooner
+        const size_t part = len - o < kFill ? len - o : kFill, to = at + o;
+        const uint8_t* from = src + o;
+        sl.job.add(pool_.submit([map, to, from, part] {
+          const size_t lo = to & ~(size_t)4095, hi = (to + part + 4095) & ~(size_t)4095;
+          (void)madvise(map + lo, hi - lo, 23 /* MADV_POPULATE_WRITE, Linux 5.14; without it the copy faults page by page */);
+          memcpy(map + to, from, part);
+        }));
+      }
+      // Taking a populated mapping down costs 0.16 s per 4 GiB: it is done behind the copies, by the pool, in steps.
+      // Segments are stored in file order and a slot is only reused once its copies are over, so everything more
+      // than 8 segments behind this one has been written.
+      const size_t lag = 8 * piece_;
+      if (at > lag) {
+        const size_t hi = (at - lag) & ~(kUnmapStep - 1);
+        if (hi > unmapped_) {
+          uint8_t* lo_p = map + unmapped_;
+          const size_t n = hi - unmapped_;
+          unmap_.add(pool_.submit([lo_p, n] { munmap(lo_p, n); }));
+          unmapped_ = hi;
+        }
+      }
+    } else {
+      sl.job.add(pool_.submit([fd, src, len, at] { pwrite_all(fd, src, len, at); }));
+    }
+  }
+  // pages for [0, upto) of the sink exist (driver thread only; no copy into the mapping runs while pages are made)
+  bool reserve(size_t upto, bool just_that = false) {
+    if (!map_ || no_alloc_) return false;
+    if (upto <= ready_) return true;
+    StepSum::Scope t(t_alloc_);
+    for (size_t i = 0; i < out_ring_.size(); ++i) out_ring_[i].job.wait();
+    const size_t end = (sink_len_ + 4095) & ~(size_t)4095;
+    size_t want = (ready_ + kAllocStep > upto && !just_that) ? ready_ + kAllocStep : (upto + 4095) & ~(size_t)4095;
+    if (want > end) want = end;
+    if (fallocate(sink_fd_, 0, (off_t)ready_, (off_t)(want - ready_)) != 0) {
+      no_alloc_ = true;
+      return false;
+    }
+    ready_ = want;
+    return true;
+  }
+  void prefetch(size_t upto) {
+    const size_t np = pieces();
+    for (; next_read_ < np && next_read_ < upto; ++next_read_) {
+      const int si = acquire(in_ring_, in_next_);
+      Slot& sl = in_ring_[si];
+      uint8_t* dst = sl.buf.u8();
+      const size_t k = next_read_, off = base_ + k * piece_, pad = padded(k);
+      const size_t avail = base_ + total_ - off, want = own(k) + extra_;
+      const size_t len = want < avail ? want : avail;
+      const int fd = fd_;
+      for (size_t o = 0; o < len || o == 0; o += kFill) {  // several threads per piece: one pread moves 6-9 GB/s
+        const size_t part = len - o < kFill ? len - o : kFill;
+        const bool tail = o + part >= len;
+        sl.job.add(pool_.submit([fd, dst, o, part, off, len, pad, tail] {
+          pread_all(fd, dst + o, part, off + o);
+          if (tail && pad > len) memset(dst + len, 0, pad - len);
+        }));
+      }
+      pend_.push_back(si);
+    }
+  }
+  void quiesce() {  // nothing may still touch the rings when they are freed
+    for (size_t i = 0; i < in_ring_.size(); ++i) in_ring_[i].job.wait();
+    for (size_t i = 0; i < out_ring_.size(); ++i) out_ring_[i].job.wait();
+    unmap_.wait();
+    pre_stop_ = true;
+    pre_job_.wait();
+    if (map_) munmap(map_ + unmapped_, sink_len_ - unmapped_);
+    if (in_s_.live()) ghf_sync(in_s_.ctx());
+    if (out_s_.live()) ghf_sync(out_s_.ctx());
+  }
+  StepSum t_read_, t_slot_, t_land_, t_alloc_, t_flush_;
+  Session in_s_, run_s_, out_s_;
+  size_t piece_;
+  Ring in_ring_, out_ring_;
+  size_t in_next_, out_next_;
+  int fd_;
+  size_t base_, total_, extra_, next_read_, next_feed_;
+  std::deque<int> pend_;  // slots of the reads that were started and not fed yet, in piece order
+  std::deque<Landing> landing_;
+  int sink_fd_;
+  size_t sink_len_, ready_, unmapped_ = 0;
+  uint8_t* map_;
+  bool sized_, no_alloc_;
+  Jobs unmap_, pre_job_;
+  int pre_fd_ = -1, pre_fd_last_ = -1;
+  std::atomic<size_t> pre_done_{0};
+  std::atomic<bool> pre_stop_{false};
+  IoPool pool_;           // last member: its threads stop before anything above goes away
+};
+
 }  // namespace detail
 
 // ------------------------------------------------------------------------------------------------ Compressor
@@ -228,87 +744,242 @@ class HipCanonicalHuffEncoder<unsigned char> {
     infile_ = fopen(infile_name.c_str(), "rb");
     if (!infile_) throw Error(GHF_E_INVAL, "cannot open input file " + infile_name);
     if (outfile_name.empty()) outfile_name = infile_name + ".crs2";
-    outfile_ = fopen(outfile_name.c_str(), "wb");
+    outfile_ = fopen(outfile_name.c_str(), "w+b");  // read-write: the pipeline maps it
     if (!outfile_) throw Error(GHF_E_INVAL, "cannot open output file " + outfile_name);
   }
 
   void clear() {  // include/encoder.h:85-92
+    if (pipe_) pipe_->cancel_presize();  // nothing may still be making pages for a file that is about to be closed
     if (infile_) fclose(infile_);
     if (outfile_) fclose(outfile_);
     infile_ = NULL;
     outfile_ = NULL;
   }
 
-  // include/encoder.h:99-105,123-150: the file goes to the GPU once and stays there for encode_file
+  // include/encoder.h:99-105,123-150 -- pass 1 over the file: piece k is counted (K1, accumulating) while piece k+1
+  // is on the PCIe bus and pieces k+2.. are being read.  A file of up to GHF_RESIDENT_BYTES (default 64 GiB of the
+  // 288) stays in HBM for encode_file; a larger one is read a second time there, as the reference does
+  // (include/canonical_huff_encoder.cc:247-248 rewinds the input), through a ring of kRing piece buffers.
   void caculate_frequency() {
+    detail::StepTimer timer_("caculate_frequency");
     n_ = detail::file_size(infile_);
     if (n_ == 0) throw Error(GHF_E_EMPTY, "empty input: undefined in the reference, refused here");
-    d_in_.alloc(s_, n_ + 16);
-    d_hist_.alloc(s_, GHF_NSYM * sizeof(uint64_t));
-    stager_.to_device(infile_, d_in_.u8(), n_, infile_name_);  // pieces: fread overlaps hipMemcpyAsync
-    s_.check(ghf_histogram(s_.ctx(), d_in_.u8(), n_, static_cast<uint64_t*>(d_hist_.p)), "ghf_histogram");
+    pipe().begin();
+    const detail::Session& run = pipe().run();
+    const size_t P = pipe().piece(), np = (n_ + P - 1) / P;
+    resident_ = n_ <= detail::env_bytes("GHF_RESIDENT_BYTES", (size_t)64 << 30);
+    if (resident_ && d_in_.n < n_ + 16) {
+      try {
+        d_in_.alloc(run, n_ + 16);
+      } catch (const Error&) {
+        resident_ = false;
+      }
+    }
+    if (!resident_) {
+      d_in_.reset();
+      for (int r = 0; r < kRing; ++r)
+        if (d_ring_[r].n < P + 16) d_ring_[r].alloc(run, P + 16);
+    }
+    if (!d_hist_.p) d_hist_.alloc(run, GHF_NSYM * sizeof(uint64_t));
+    uint64_t* hist = static_cast<uint64_t*>(d_hist_.p);
+    run.check(ghf_memset_d(run.ctx(), hist, 0, GHF_NSYM * sizeof(uint64_t)), "ghf_memset_d");
+    pipe().open_feed(fileno(infile_), 0, n_, 0);
+    for (size_t k = 0; k < np; ++k) {
+      const int r = (int)(k % kRing);
+      uint8_t* dst = piece_at(k);
+      if (!resident_) used_[r].hold(pipe().in());  // K1 of piece k - kRing has let go of this buffer
+      pipe().feed(dst, arrived_[r]);
+      arrived_[r].hold(run);
+      run.check(ghf_histogram_add(run.ctx(), dst, pipe().own(k), hist), "ghf_histogram_add");
+      used_[r].record(run);
+      if (k == 0 && np > 2) {  // the first piece's counts come back early: how big will the output be, roughly?
+        if (!h_first_.p) h_first_.alloc(run, GHF_NSYM * sizeof(uint64_t));
+        run.check(ghf_copy_d2h(run.ctx(), h_first_.p, hist, GHF_NSYM * sizeof(uint64_t)), "ghf_copy_d2h");
+        first_counted_.record(run);
+      }
+      if (k == 1 && np > 2) presize_from_first_piece();
+    }
+    run.sync("caculate_frequency");
   }
 
   // include/canonical_huff_encoder.cc:35-42
   void gen_encode() {
-    d_code_.alloc(s_, sizeof(ghf_code));
+    detail::StepTimer timer_("gen_encode");
+    const detail::Session& run = pipe().run();
+    if (!d_code_.p) d_code_.alloc(run, sizeof(ghf_code));
     // opt-in: set_code_limit(true) or GHF_CODE_LIMIT=1 in the environment replaces the reference's
     // "undefined above 32 bits" by the optimal 32-bit-limited code; without it the behaviour is the reference's
     const char* env = getenv("GHF_CODE_LIMIT");
     const unsigned flags = (limit_ || (env && env[0] == '1')) ? GHF_CODE_LIMIT : 0u;
-    s_.check(ghf_build_code_ex(s_.ctx(), static_cast<const uint64_t*>(d_hist_.p), static_cast<ghf_code*>(d_code_.p), flags),
-             "ghf_build_code");
-    s_.check(ghf_copy_d2h(s_.ctx(), &code_, d_code_.p, sizeof(ghf_code)), "ghf_copy_d2h");
-    s_.sync("gen_encode");
+    run.check(ghf_build_code_ex(run.ctx(), static_cast<const uint64_t*>(d_hist_.p), static_cast<ghf_code*>(d_code_.p), flags),
+              "ghf_build_code");
+    run.check(ghf_copy_d2h(run.ctx(), &code_, d_code_.p, sizeof(ghf_code)), "ghf_copy_d2h");
+    uint64_t hist[GHF_NSYM];
+    run.check(ghf_copy_d2h(run.ctx(), hist, d_hist_.p, sizeof hist), "ghf_copy_d2h");
+    run.sync("gen_encode");
+    uint64_t bits = code_.length[256];  // the body's size follows from the counts: the output file is sized up front
+    for (int b = 0; b < 256; ++b) bits += hist[b] * code_.length[b];
+    out_bytes_ = ghf_header_bytes(code_.max_len) + (size_t)((bits + 7) >> 3);
   }
 
   // include/canonical_huff_encoder.cc:210-242: header at file offset 0, flushed before the body is produced
   void write_encode_info() {
+    detail::StepTimer timer_("write_encode_info");
+    const detail::Session& run = pipe().run();
     const size_t hdr = ghf_header_bytes(code_.max_len);
-    cap_ = ghf_compress_bound(n_);
-    d_out_.alloc(s_, cap_);
-    h_out_.alloc(s_, 2048);  // the header only (<= 1296 bytes); the body is streamed through the stager
-    s_.check(ghf_write_header(s_.ctx(), static_cast<const ghf_code*>(d_code_.p), d_out_.u8(), cap_), "ghf_write_header");
-    s_.check(ghf_copy_d2h(s_.ctx(), h_out_.p, d_out_.p, hdr), "ghf_copy_d2h");
-    s_.sync("write_encode_info");
+    if (!d_hdr_.p) d_hdr_.alloc(run, 2048);  // the largest header is 1040 + 8 * 32 = 1296 bytes
+    if (!h_hdr_.p) h_hdr_.alloc(run, 2048);
+    run.check(ghf_write_header(run.ctx(), static_cast<const ghf_code*>(d_code_.p), d_hdr_.u8(), d_hdr_.n), "ghf_write_header");
+    run.check(ghf_copy_d2h(run.ctx(), h_hdr_.p, d_hdr_.p, hdr), "ghf_copy_d2h");
+    run.sync("write_encode_info");
     fseek(outfile_, 0, SEEK_SET);
-    if (fwrite(h_out_.p, 1, hdr, outfile_) != hdr) throw Error(GHF_E_INVAL, "short write (header)");
+    if (fwrite(h_hdr_.p, 1, hdr, outfile_) != hdr) throw Error(GHF_E_INVAL, "short write (header)");
     fflush(outfile_);
   }
 
-  // include/canonical_huff_encoder.cc:245-285
+  // include/canonical_huff_encoder.cc:245-285 -- pass 2, piece by piece.  A piece is to the stream what a shard is to
+  // the multi-GPU path (include/ghf.h, ghf_encode_sharded): K4 prices it, its first bit is the running sum of the
+  // prices before it, K5 packs it at that absolute bit into a buffer of its own (GHF_EMIT_REBASE), and the D2H of
+  // piece k runs while K4/K5 work on piece k+1 and the writer threads put piece k-1 into the file at its own offset.
+  // Neighbouring pieces share one 16-byte unit of the stream (a piece does not end on a byte): that unit is OR-ed
+  // together here (`edge`), everything else goes from HBM to the file untouched.
   void encode_file() {
-    const size_t hdr = ghf_header_bytes(code_.max_len);
-    detail::DeviceBuf d_end;
-    d_end.alloc(s_, 2 * sizeof(uint64_t));
-    uint64_t end[2] = {0, 0};
-    const ghf_code* dc = static_cast<const ghf_code*>(d_code_.p);
-    s_.check(ghf_encode_plan(s_.ctx(), d_in_.u8(), n_, dc, NULL), "ghf_encode_plan");
-    s_.check(ghf_encode_emit(s_.ctx(), d_in_.u8(), n_, dc, NULL, GHF_EMIT_LAST, d_out_.u8(), cap_, NULL,
-                             static_cast<uint64_t*>(d_end.p)),
-             "ghf_encode_emit");
-    s_.check(ghf_copy_d2h(s_.ctx(), end, d_end.p, sizeof end), "ghf_copy_d2h");
-    s_.sync("encode_file");
-    const size_t total = (size_t)end[1];
-    stager_.to_file(d_out_.u8() + hdr, total - hdr, outfile_, "output (body)");  // pieces: fwrite overlaps the D2H copies
-    fflush(outfile_);
+    detail::StepTimer timer_("encode_file");
+    try {
+      encode_pieces();
+    } catch (...) {
+      pipe().abandon_sink();
+      throw;
+    }
   }
 
   const ghf_code& code() const { return code_; }  // length_/codeword_/symbol_/... of the reference, for tests
   void set_code_limit(bool on) { limit_ = on; }   // not in the reference: see gen_encode()
 
  private:
+  void encode_pieces() {
+    pipe().begin();
+    const detail::Session &run = pipe().run(), &out = pipe().out();
+    const size_t P = pipe().piece(), np = (n_ + P - 1) / P, hdr = ghf_header_bytes(code_.max_len);
+    const size_t cap = ghf_shard_bound(P);
+    for (int r = 0; r < kRing; ++r)
+      if (d_out_[r].n < cap) d_out_[r].alloc(run, cap);
+    if (!d_scal_.p) d_scal_.alloc(run, kRing * 4 * sizeof(uint64_t));
+    if (!h_scal_.p) h_scal_.alloc(run, kRing * 4 * sizeof(uint64_t) + kRing * 32);
+    uint64_t* const ds = static_cast<uint64_t*>(d_scal_.p);                 // per ring slot: total bits, start bit, end[2]
+    volatile uint64_t* const hs = static_cast<uint64_t*>(h_scal_.p);        // pinned mirror of [0..1]
+    uint8_t* const h_edge = h_scal_.u8() + kRing * 4 * sizeof(uint64_t);    // per ring slot: first unit, last unit
+    const ghf_code* dc = static_cast<const ghf_code*>(d_code_.p);
+    const int fd = fileno(outfile_);
+    if (!resident_) pipe().open_feed(fileno(infile_), 0, n_, 0);
+    pipe().open_sink(fd, out_bytes_, true);
+    detail::StepSum t_plan("wait for K4");
+    uint64_t start = 8 * (uint64_t)hdr;  // absolute stream bit of the piece's first code
+    uint8_t edge[16];                    // the unit at stream byte (start / 128) * 16, as far as it is known
+    memset(edge, 0, sizeof edge);
+    memcpy(edge, h_hdr_.u8() + (hdr & ~(size_t)15), hdr & 15);
+    struct Span {
+      bool live, last;
+      int r;
+      size_t F, U, E;  // stream bytes: first unit, unit shared with the next piece (E for the last piece), end
+    } prev = {false, false, 0, 0, 0, 0};
+    for (size_t k = 0; k < np; ++k) {
+      const int r = (int)(k % kRing);
+      const size_t len = n_ - k * P < P ? n_ - k * P : P;
+      const bool last = k + 1 == np;
+      const uint8_t* src = piece_at(k);
+      if (!resident_) {
+        used_[r].hold(pipe().in());
+        pipe().feed(piece_at(k), arrived_[r]);
+        arrived_[r].hold(run);
+      }
+      run.check(ghf_encode_plan(run.ctx(), src, len, dc, ds + 4 * r), "ghf_encode_plan");  // K4
+      run.check(ghf_copy_d2h(run.ctx(), const_cast<uint64_t*>(hs + 4 * r), ds + 4 * r, sizeof(uint64_t)), "ghf_copy_d2h");
+      planned_[r].record(run);
+      if (prev.live) close_span(prev.r, prev.F, prev.U, prev.E, prev.last, edge, h_edge, fd);  // while K4 runs
+      {
+        detail::StepSum::Scope t(t_plan);
+        planned_[r].sync();
+      }
+      const uint64_t total = hs[4 * r];
+      hs[4 * r + 1] = start;
+      run.check(ghf_copy_h2d(run.ctx(), ds + 4 * r + 1, const_cast<uint64_t*>(hs + 4 * r + 1), sizeof(uint64_t)), "ghf_copy_h2d");
+      fetched_[r].hold(run);  // the D2H of piece k - kRing has let go of d_out_[r]
+      run.check(ghf_encode_emit(run.ctx(), src, len, dc, ds + 4 * r + 1, GHF_EMIT_REBASE | (last ? GHF_EMIT_LAST : 0),
+                                d_out_[r].u8(), cap, NULL, ds + 4 * r + 2),
+                "ghf_encode_emit");  // K5
+      used_[r].record(run);
+      emitted_[r].record(run);
+      uint64_t end = start + total;
+      if (last) end = (end + code_.length[256] + 7) & ~(uint64_t)7;  // end mark, then 1-bits up to the byte
+      Span sp = {true, last, r, (size_t)(start >> 7) << 4, 0, (size_t)((end + 7) >> 3)};
+      sp.U = last ? sp.E : (size_t)(end >> 7) << 4;
+      // d_out_[r][0] is stream byte F.  The unit at F and the one at U are shared with the neighbours: to the host.
+      emitted_[r].hold(out);
+      const size_t nfirst = sp.E - sp.F < 16 ? sp.E - sp.F : 16;
+      out.check(ghf_copy_d2h(out.ctx(), h_edge + 32 * r, d_out_[r].p, nfirst), "ghf_copy_d2h");
+      if (!last && sp.U > sp.F && sp.E > sp.U)
+        out.check(ghf_copy_d2h(out.ctx(), h_edge + 32 * r + 16, d_out_[r].u8() + (sp.U - sp.F), sp.E - sp.U), "ghf_copy_d2h");
+      edged_[r].record(out);
+      if (sp.U > sp.F + 16) pipe().drain(emitted_[r], d_out_[r].u8() + 16, sp.U - sp.F - 16, fd, sp.F + 16);
+      fetched_[r].record(out);
+      prev = sp;
+      start += total;
+    }
+    close_span(prev.r, prev.F, prev.U, prev.E, prev.last, edge, h_edge, fd);
+    pipe().close_sink(prev.E);
+    run.sync("encode_file");
+    if (prev.E != out_bytes_) throw Error(GHF_E_CORRUPT, "encode_file: the pieces do not add up to the size the counts give");
+    fseek(outfile_, 0, SEEK_END);
+  }
   HipCanonicalHuffEncoder(const HipCanonicalHuffEncoder&);
   HipCanonicalHuffEncoder& operator=(const HipCanonicalHuffEncoder&);
-  detail::Session s_;
+  static const int kRing = 3;
+  uint8_t* piece_at(size_t k) const { return resident_ ? d_in_.u8() + k * pipe().piece_bytes() : d_ring_[k % kRing].u8(); }
+  // While pass 1 still reads the file, a pool thread already makes the output file's pages (Pipe::presize): 97 % of
+  // the order-0 entropy of the first piece, times the file size.  An estimate only -- encode_file() sizes the file
+  // exactly (the rest of the pages, or a cut) before it writes a byte.
+  void presize_from_first_piece() {
+    first_counted_.sync();
+    const volatile uint64_t* h = static_cast<const uint64_t*>(h_first_.p);
+    double total = 0, bits = 0;
+    for (int b = 0; b < 256; ++b) total += (double)h[b];
+    for (int b = 0; b < 256; ++b)
+      if (h[b]) bits -= (double)h[b] * log2((double)h[b] / total);
+    if (total <= 0) return;
+    double per_symbol = bits / total;
+    if (per_symbol < 1) per_symbol = 1;  // no code is shorter than one bit
+    pipe().presize(fileno(outfile_), (size_t)(0.97 * per_symbol / 8 * (double)n_));
+  }
+  // the piece in ring slot r has reached the host as far as the host needs it: settle the unit it shares with its
+  // predecessor, write it out if the piece has moved past it, and open the next one
+  void close_span(int r, size_t F, size_t U, size_t E, bool last, uint8_t* edge, const uint8_t* h_edge, int fd) {
+    edged_[r].sync();
+    const uint8_t* first = h_edge + 32 * r;
+    const size_t nfirst = E - F < 16 ? E - F : 16;
+    for (size_t i = 0; i < nfirst; ++i) edge[i] |= first[i];
+    if (last) {
+      detail::pwrite_all(fd, edge, nfirst, F);
+    } else if (U > F) {
+      detail::pwrite_all(fd, edge, 16, F);
+      memset(edge, 0, 16);
+      memcpy(edge, first + 16, E - U);
+    }  // else the piece ends inside the unit it began in: the unit stays open
+  }
+  detail::Pipe& pipe() const {
+    if (!pipe_) pipe_ = detail::Pipe::shared();
+    return *pipe_;
+  }
+  mutable std::shared_ptr<detail::Pipe> pipe_;  // first member: the buffers below are freed through its contexts
   FILE* infile_;
   FILE* outfile_;
   std::string infile_name_;
-  size_t n_, cap_;
+  size_t n_, out_bytes_ = 0;
+  bool resident_ = true;
   bool limit_ = false;
-  detail::PinnedBuf h_out_;
-  detail::DeviceBuf d_in_, d_hist_, d_code_, d_out_;
-  detail::Stager stager_;
+  detail::PinnedBuf h_hdr_, h_scal_, h_first_;
+  detail::DeviceBuf d_in_, d_ring_[kRing], d_hist_, d_code_, d_hdr_, d_out_[kRing], d_scal_;
+  detail::Event arrived_[kRing], used_[kRing], planned_[kRing], emitted_[kRing], fetched_[kRing], edged_[kRing], first_counted_;
   ghf_code code_;
 };
 
@@ -324,7 +995,7 @@ class HipCanonicalHuffDecoder<unsigned char> {
     infile_ = fopen(infile_name.c_str(), "rb");
     if (!infile_) throw Error(GHF_E_INVAL, "cannot open input file " + infile_name);
     if (outfile_name.empty()) outfile_name = infile_name + ".de";
-    outfile_ = fopen(outfile_name.c_str(), "wb");
+    outfile_ = fopen(outfile_name.c_str(), "w+b");  // read-write: the pipeline maps it
     if (!outfile_) {
       fclose(infile_);
       throw Error(GHF_E_INVAL, "cannot open output file " + outfile_name);
@@ -337,38 +1008,154 @@ class HipCanonicalHuffDecoder<unsigned char> {
 
   // include/canonical_huff_encoder.cc:349-374 -- plus the validation the reference does not do
   void get_encode_info() {
+    detail::StepTimer timer_("get_encode_info");
     n_ = detail::file_size(infile_);
     std::vector<uint8_t> head(n_ < 1296 ? n_ : 1296);  // the largest header: 1040 + 8 * 32
     if (fread(head.data(), 1, head.size(), infile_) != head.size()) throw Error(GHF_E_INVAL, "short read");
-    s_.check(ghf_parse_header(head.data(), head.size(), &code_, &hdr_), "ghf_parse_header");
+    pipe().run().check(ghf_parse_header(head.data(), head.size(), &code_, &hdr_), "ghf_parse_header");
     fseek(infile_, 0, SEEK_SET);
   }
 
-  // include/canonical_huff_encoder.cc:377-419 (and :422-461, :519-568): runs until the end mark
+  // include/canonical_huff_encoder.cc:377-419 (and :422-461, :519-568): runs until the end mark.
+  // The body is cut at byte positions into pieces.  A .crs2 file has no sync points, but the bit at which piece k's
+  // last code ends is where piece k+1's first code begins, so one K6 pass per piece (ghf_sync_piece, exact first bit
+  // in, landing bit and symbol count out) both rebuilds the piece's side-car and hands the cut to the next piece; K7
+  // then decodes the piece block-parallel.  Piece k+1.. are read and copied in while K6/K7 run on piece k, and the
+  // decoded bytes of piece k-1 leave through the copy-out stream and the writer threads at their own file offset.
   void decode_file() {
-    d_in_.alloc(s_, n_ + 16);
-    d_code_.alloc(s_, sizeof(ghf_code));
-    stager_.to_device(infile_, d_in_.u8(), n_, "input");
-    s_.check(ghf_copy_h2d(s_.ctx(), d_code_.p, &code_, sizeof(ghf_code)), "ghf_copy_h2d");
-    const ghf_code* dc = static_cast<const ghf_code*>(d_code_.p);
-    uint64_t n_out = 0;
-    s_.check(ghf_decoded_size(s_.ctx(), d_in_.u8(), n_, dc, &n_out), "ghf_decoded_size");
-    d_out_.alloc(s_, (size_t)n_out + 16);
-    s_.check(ghf_decode(s_.ctx(), d_in_.u8(), n_, dc, NULL, d_out_.u8(), (size_t)n_out + 16, NULL), "ghf_decode");
-    s_.sync("decode_file");
-    stager_.to_file(d_out_.u8(), (size_t)n_out, outfile_, "output");
-    fflush(outfile_);
+    detail::StepTimer timer_("decode_file");
+    try {
+      decode_pieces();
+    } catch (...) {
+      pipe().abandon_sink();
+      throw;
+    }
   }
 
  private:
+  void decode_pieces() {
+    pipe().begin();
+    const detail::Session &run = pipe().run(), &out = pipe().out();
+    const size_t P = pipe().piece(), body = n_ - hdr_;
+    if (!d_code_.p) d_code_.alloc(run, sizeof(ghf_code));
+    run.check(ghf_copy_h2d(run.ctx(), d_code_.p, &code_, sizeof(ghf_code)), "ghf_copy_h2d");
+    const ghf_code* dc = static_cast<const ghf_code*>(d_code_.p);
+    pipe().open_feed(fileno(infile_), hdr_, body, 16);
+    // a compressed piece decodes to at most 8 symbols per byte (no code is shorter than one bit)
+    const size_t np = pipe().pieces(), in_cap = P + 64, out_cap = 8 * P + 64;
+    for (int r = 0; r < kRing; ++r)
+      if (d_in_[r].n < in_cap) d_in_[r].alloc(run, in_cap);
+    const int fd = fileno(outfile_);
+    pipe().open_sink(fd, 8 * body + 16, false);  // the format does not say how much comes out
+    // Where the decoded bytes wait for the file.  Making the output file's pages is the slowest stage (20 GB/s, and no
+    // copy into the file may run meanwhile), and how many are needed is only known at the end mark.  So: the first
+    // piece tells the ratio; if the estimated output fits GHF_RESIDENT_BYTES it ALL stays in HBM (`whole`) while a pool
+    // thread makes 97 % of the estimated pages, and it leaves in one sweep at the end, when the exact size is known.
+    // Otherwise (or once `whole` is full) a piece leaves as soon as it is decoded, through the kOut-deep ring.
+    struct Held {
+      const uint8_t* d;
+      size_t bytes, at;
+    };
+    std::vector<Held> held;
+    size_t whole_used = 0;
+    bool resident = false;
+    size_t fed = 0, out_off = 0;
+    uint32_t first = 0;  // the header ends on a byte
+    detail::StepSum t_sync("ghf_sync_piece"), t_mem("hipMalloc (output)");
+    bool done = false;
+    const double loop_t0 = detail::StepTimer::now();
+    for (size_t k = 0; k < np && !done; ++k) {
+      for (; fed < np && fed < k + kRing - 1; ++fed) {  // pieces k+1.. arrive while this one is worked on
+        const int q = (int)(fed % kRing);
+        used_[q].hold(pipe().in());
+        pipe().feed(d_in_[q].u8(), arrived_[q]);
+      }
+      const int r = (int)(k % kRing), o = (int)(k % kOut);
+      arrived_[r].hold(run);
+      uint64_t landing = 0, nsym = 0;
+      int has_end = 0;
+      {
+        detail::StepSum::Scope t(t_sync);
+        run.check(ghf_sync_piece(run.ctx(), d_in_[r].u8(), pipe().padded(k), first, 8 * (uint64_t)pipe().own(k), dc, &landing, &nsym,
+                                 &has_end),
+                  "ghf_sync_piece");  // K6; the call waits for its own result
+      }
+      if (nsym > out_cap) throw Error(GHF_E_CORRUPT, "a piece decodes to more than 8 symbols per byte");
+      if (k == 0 && np > 2 && !has_end && detail::Pipe::wants_map(8 * body)) {
+        const double est = (double)nsym / (double)pipe().own(0) * (double)body;
+        const size_t want = (size_t)(est * 1.05) + 4 * out_cap;
+        if (want <= detail::env_bytes("GHF_RESIDENT_BYTES", (size_t)64 << 30)) {
+          try {
+            detail::StepSum::Scope t(t_mem);
+            if (whole_.n < want) whole_.alloc(run, want);
+            resident = true;
+            pipe().presize(fd, (size_t)(est * 0.97));
+          } catch (const Error&) {
+            resident = false;
+          }
+        }
+      }
+      if (resident && whole_used + nsym > whole_.n) {  // the estimate was too low: what is held leaves now, the rest streams
+        resident = false;
+        pipe().cancel_presize();
+        pipe().adopt_presized(fd);
+        sweep(held, fd);
+      }
+      uint8_t* dst = resident ? whole_.u8() + whole_used : NULL;
+      if (nsym) {
+        if (!resident) {
+          if (d_out_[o].n < out_cap) d_out_[o].alloc(run, out_cap);
+          fetched_[o].hold(run);  // the D2H of piece k - kOut has let go of d_out_[o]
+          dst = d_out_[o].u8();
+        }
+        run.check(ghf_decode(run.ctx(), d_in_[r].u8(), pipe().padded(k), dc, NULL, dst, out_cap, NULL), "ghf_decode");  // K7
+      }
+      used_[r].record(run);
+      if (nsym && resident) {
+        const Held h = {dst, (size_t)nsym, out_off};
+        held.push_back(h);
+        whole_used += ((size_t)nsym + 255) & ~(size_t)255;
+      } else if (nsym) {
+        decoded_[o].record(run);
+        pipe().drain(decoded_[o], dst, (size_t)nsym, fd, out_off);
+        fetched_[o].record(out);
+      }
+      out_off += (size_t)nsym;
+      first = (uint32_t)landing;
+      done = has_end != 0;
+    }
+    if (getenv("GHF_PIPE_TRACE")) fprintf(stderr, "[ghf]   %-18s %9.2f ms\n", "piece loop", detail::StepTimer::now() - loop_t0);
+    if (resident) {
+      pipe().cancel_presize();  // (it has long finished, or the estimate was too high: the exact size is known now)
+      pipe().adopt_presized(fd);
+      pipe().reserve_all(out_off);
+      sweep(held, fd);
+    }
+    pipe().close_sink(out_off);
+    run.sync("decode_file");
+    fseek(outfile_, 0, SEEK_END);
+    if (!done) throw Error(GHF_E_CORRUPT, "the stream ends before the end mark");
+  }
+  // everything that was decoded into `whole_` so far goes to the file
+  template <typename V>
+  void sweep(V& held, int fd) {
+    swept_.record(pipe().run());
+    for (size_t i = 0; i < held.size(); ++i) pipe().drain(swept_, held[i].d, held[i].bytes, fd, held[i].at);
+    held.clear();
+  }
   HipCanonicalHuffDecoder(const HipCanonicalHuffDecoder&);
   HipCanonicalHuffDecoder& operator=(const HipCanonicalHuffDecoder&);
-  detail::Session s_;
+  static const int kRing = 3, kOut = 2;
+  detail::Pipe& pipe() const {
+    if (!pipe_) pipe_ = detail::Pipe::shared();
+    return *pipe_;
+  }
+  mutable std::shared_ptr<detail::Pipe> pipe_;  // first member: the buffers below are freed through its contexts
   FILE* infile_;
   FILE* outfile_;
   size_t n_, hdr_;
-  detail::DeviceBuf d_in_, d_code_, d_out_;
-  detail::Stager stager_;
+  detail::DeviceBuf d_in_[kRing], d_code_, d_out_[kOut], whole_;
+  detail::Event arrived_[kRing], used_[kRing], decoded_[kOut], fetched_[kOut], swept_;
   ghf_code code_;
 };
 

@@ -94,11 +94,30 @@ int ghf_copy_h2d(ghf_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /*
 int ghf_copy_d2h(ghf_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* async on the stream */
 int ghf_memset_d(ghf_ctx* ctx, void* d_dst, int value, size_t bytes);
 
+/* ---- events: ordering between the streams of several contexts without stopping the host ----------
+ * (the file pipeline of golden-huffman_amd/host/glzip_hip.h, which replaces the reference's 64 KiB
+ * Buffer, utils/include/buffer.h:61-317, keeps one context per direction: copy-in, kernels, copy-out).
+ * record: the event completes when everything enqueued on ctx's stream so far has.  wait: ctx's stream
+ * does not run anything enqueued after this call before the event has completed (no host wait).
+ * sync: the host waits.  An event that was never recorded counts as complete. */
+typedef struct ghf_event ghf_event;
+int ghf_event_create(ghf_ctx* ctx, ghf_event** out);
+int ghf_event_destroy(ghf_event* ev);
+int ghf_event_record(ghf_ctx* ctx, ghf_event* ev);
+int ghf_event_wait(ghf_ctx* ctx, ghf_event* ev);
+int ghf_event_sync(ghf_event* ev);
+
 /* ---- K1: Encoder::do_init + do_caculate_frequency, include/encoder.h:123-129,136-150 ------------
  * d_hist[0..255] = byte counts of d_in[0..n), d_hist[256] = 1.  d_in needs no alignment (16-byte
  * aligned input takes the fast path).  Also leaves per-chunk histograms in the context so that a
- * following ghf_encode_plan on the same (d_in, n) does not re-read the input. */
+ * following ghf_encode_plan on the same (d_in, n) does not re-read the input -- the caller must not
+ * change d_in[0..n) between the two calls. */
 int ghf_histogram(ghf_ctx* ctx, const uint8_t* d_in, size_t n, uint64_t* d_hist);
+/* The same, for an input that arrives in pieces (the reference counts while it refills its buffer,
+ * include/encoder.h:136-150): d_hist[0..255] += byte counts of d_in[0..n), d_hist[256] = 1.  The caller
+ * zeroes d_hist (ghf_memset_d) before the first piece.  Keeps nothing for ghf_encode_plan (a piece's
+ * buffer is usually refilled in between). */
+int ghf_histogram_add(ghf_ctx* ctx, const uint8_t* d_in, size_t n, uint64_t* d_hist);
 
 /* ---- K2+K3: CanonicalHuffEncoder::gen_encode = get_encoding_length + do_gen_encode,
  *      include/canonical_huff_encoder.cc:35-42,289-345,69-141 -- on ONE wavefront, emulating

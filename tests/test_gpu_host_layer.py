@@ -79,8 +79,118 @@ def test_errors_are_reported_not_undefined(tool, tmp_path):
     assert subprocess.run([tool, str(tmp_path / "missing.bin"), "3"], capture_output=True, timeout=60).returncode == 1
 
 
+def _env(**kw):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in kw.items()})
+    return e
+
+
+def _shm_dir(tmp_path):
+    """multi-GiB files live in /dev/shm (what SURVEY 8f N1's file-to-file rate is quoted on) when it is there"""
+    import tempfile
+
+    if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK):
+        return tempfile.TemporaryDirectory(dir="/dev/shm", prefix="ghf_")
+    return tempfile.TemporaryDirectory(dir=str(tmp_path))
+
+
+@pytest.mark.parametrize("resident,sink", [(1 << 40, "mmap"), (0, "pwrite"), (0, "mmap")], ids=["resident-mmap", "reread-pwrite", "reread-mmap"])
+@pytest.mark.parametrize("name", ["text_1m", "zipf_64k", "fib32_maxlen32", "uniform_65537", "single_x", "aaaabbc"])
+def test_pipeline_small_pieces_many_edges(tool, tmp_path, golden, name, resident, sink):
+    """64 KiB pieces: every piece boundary falls inside a 16-byte unit of the stream that two pieces share; with
+    GHF_RESIDENT_BYTES=0 the encoder reads the file a second time through its ring instead of keeping it in HBM;
+    GHF_SINK picks how the output file is filled (shared mapping over fallocate-d pages, or pwrite).  The .crs2 must
+    still be the reference's bytes and decode piece by piece"""
+    data = CASES[name]()
+    f = tmp_path / (name + ".bin")
+    data.tofile(f)
+    env = _env(GHF_PIECE_BYTES=65536, GHF_RESIDENT_BYTES=resident, GHF_IO_THREADS=3, GHF_SINK=sink)
+    assert subprocess.run([tool, str(f), "3"], timeout=120, env=env).returncode == 0
+    crs = np.fromfile(str(f) + ".crs2", dtype=np.uint8)
+    assert crs.size == golden[name]["crs2_bytes"] and sha(crs) == golden[name]["crs2_sha256"]
+    assert subprocess.run([tool, str(f) + ".crs2", "4"], timeout=120, env=env).returncode == 0
+    assert np.array_equal(np.fromfile(str(f) + ".crs2.de", dtype=np.uint8), data)
+
+
+def test_pipeline_estimates_that_miss(tool, tmp_path):
+    """both policies size the output file from their first piece before they know better: a file that starts
+    incompressible and goes on as zeros makes the encoder's guess 6x too high (the file is cut back) and the decoder's
+    too low (its HBM-resident output overflows: what it holds is swept out and the rest streams through the ring)"""
+    import datagen as dg
+
+    data = np.concatenate([dg.uniform_bytes(256 << 10, seed=3), np.zeros(16 << 20, dtype=np.uint8), dg.uniform_bytes(64 << 10, seed=4)])
+    f = tmp_path / "skew.bin"
+    data.tofile(f)
+    env = _env(GHF_PIECE_BYTES=65536, GHF_SINK="mmap")
+    assert subprocess.run([tool, str(f), "3"], timeout=120, env=env).returncode == 0
+    crs = np.fromfile(str(f) + ".crs2", dtype=np.uint8)
+    ref = orc.compress(data)
+    assert crs.size == ref.size and sha(crs) == sha(ref)
+    assert subprocess.run([tool, str(f) + ".crs2", "5"], timeout=120, env=env).returncode == 0
+    assert np.array_equal(np.fromfile(str(f) + ".crs2.de", dtype=np.uint8), data)
+    # and the other way round: zeros first, noise behind (encoder guesses low, decoder high)
+    data = data[::-1].copy()
+    data.tofile(f)
+    assert subprocess.run([tool, str(f), "3"], timeout=120, env=env).returncode == 0
+    crs = np.fromfile(str(f) + ".crs2", dtype=np.uint8)
+    ref = orc.compress(data)
+    assert crs.size == ref.size and sha(crs) == sha(ref)
+    assert subprocess.run([tool, str(f) + ".crs2", "6"], timeout=120, env=env).returncode == 0
+    assert np.array_equal(np.fromfile(str(f) + ".crs2.de", dtype=np.uint8), data)
+
+
+def test_pipeline_truncated_and_trailing_bytes(tool, tmp_path):
+    """a body cut before the end mark is an error; bytes behind the end mark are ignored, as in the reference
+    (its decoders stop at the mark, include/canonical_huff_encoder.cc:404-411)"""
+    import datagen as dg
+
+    data = dg.zipf_bytes(3 << 20, seed=5)
+    crs = orc.compress(data)
+    env = _env(GHF_PIECE_BYTES=1 << 20)
+    cut = tmp_path / "cut.crs2"
+    crs[: crs.size - (1 << 20) - 7].tofile(cut)
+    r = subprocess.run([tool, str(cut), "4"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 1 and "error 7" in r.stderr
+    more = tmp_path / "more.crs2"
+    np.concatenate([crs, np.full((2 << 20) + 3, 0xA5, dtype=np.uint8)]).tofile(more)
+    assert subprocess.run([tool, str(more), "4"], timeout=120, env=env).returncode == 0
+    assert np.array_equal(np.fromfile(str(more) + ".de", dtype=np.uint8), data)
+
+
+def test_pipeline_multi_gib_file_bit_exact_and_rate(tool, tmp_path):
+    """2.2 GiB in /dev/shm: 141 pieces of 16 MiB.  The .crs2 equals the oracle's byte for byte, the round trip gives
+    the file back, and ghf_tool's mode 7 reports the file-to-file rates (kept in gpurun_out/ for DESIGN.md)."""
+    import json
+
+    import datagen as dg
+
+    n = (2200 << 20) + 4321
+    with _shm_dir(tmp_path) as d:
+        f = os.path.join(d, "big.bin")
+        base = dg.zipf_bytes(32 << 20, seed=2024)  # tiled with a different rotation per tile (the generator is slow)
+        data = np.empty(n, dtype=np.uint8)
+        for t, lo in enumerate(range(0, n, base.size)):
+            hi = min(n, lo + base.size)
+            data[lo:hi] = np.roll(base, 4099 * t)[: hi - lo]
+        data.tofile(f)
+        want = sha(orc.compress(data))
+        r = subprocess.run([tool, f, "7"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rep = json.loads(r.stdout.strip().splitlines()[-1])
+        assert rep["round_trip_ok"] is True
+        h = hashlib.sha256()
+        with open(f + ".crs2", "rb") as fh:
+            for blk in iter(lambda: fh.read(1 << 24), b""):
+                h.update(blk)
+        assert h.hexdigest() == want
+        out = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out):
+            with open(os.path.join(out, "file_to_file_zipf_2200MiB.json"), "w") as fh:
+                json.dump(rep, fh)
+
+
 def test_streaming_stager_multi_piece_file(tool, tmp_path):
-    """a 70 MiB file = three 32 MiB staging pieces each way (double-buffered pinned buffers, two copy streams)"""
+    """a 70 MiB file = five 16 MiB pieces each way through the pipeline (reader/writer threads, pinned rings, three streams)"""
     import datagen as dg
 
     data = dg.zipf_bytes((70 << 20) + 12345, seed=77)
