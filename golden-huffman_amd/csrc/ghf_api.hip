@@ -783,7 +783,8 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
     index = &c->fidx;
   }
   if (!index->d_chunk_bit || !index->d_seg_bit || index->seg_symbols != (uint32_t)kSegSymbols ||
-      index->chunk_symbols != (uint32_t)kBlockSymbols || index->n_segs != (index->n_symbols + kSegSymbols - 1) / kSegSymbols)
+      index->chunk_symbols != (uint32_t)kBlockSymbols || index->n_segs != (index->n_symbols + kSegSymbols - 1) / kSegSymbols ||
+      index->n_chunks != (index->n_symbols + kBlockSymbols - 1) / kBlockSymbols)
     return fail(c, GHF_E_INVAL, "ghf_decode: malformed index");
   if (cap < index->n_symbols) return fail(c, GHF_E_CAP, "ghf_decode: output capacity below n_symbols");
   DecParams p;
@@ -811,6 +812,7 @@ int ghf_crs_build_code(ghf_ctx* c, const uint64_t* d_hist, ghf_tree* d_tree, ghf
   launch_crs_build_code(d_hist, d_tree, d_code, c->d_u64 + 6, c->d_status, c->stream);
   GHF_HIP(c, hipGetLastError());
   c->plan_in = nullptr;  // d_code changed: a cached plan no longer describes it
+  if (c->dt_code == d_code) c->dt_code = nullptr;  // ... and neither do decode tables prepared from it
   return GHF_OK;
 }
 
@@ -952,7 +954,8 @@ int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int
     index = &c->fidx;
   }
   if (!index->d_chunk_bit || !index->d_seg_bit || index->seg_symbols != (uint32_t)kSegSymbols ||
-      index->chunk_symbols != (uint32_t)kBlockSymbols || index->n_segs != (index->n_symbols + kSegSymbols - 1) / kSegSymbols)
+      index->chunk_symbols != (uint32_t)kBlockSymbols || index->n_segs != (index->n_symbols + kSegSymbols - 1) / kSegSymbols ||
+      index->n_chunks != (index->n_symbols + kBlockSymbols - 1) / kBlockSymbols)
     return fail(c, GHF_E_INVAL, "ghf_crs_decode: malformed index");
   if (cap < index->n_symbols) return fail(c, GHF_E_CAP, "ghf_crs_decode: output capacity below n_symbols");
   DecParams p;

@@ -15,9 +15,42 @@ __global__ __launch_bounds__(256) void k_build_decode_tables(const ghf_code* __r
                                                              int* __restrict__ status) {
   __shared__ uint32_t fcl[36];
   __shared__ uint32_t sp[36];
+  __shared__ unsigned long long kraft;
+  __shared__ int bad;
   const int tid = threadIdx.x;
   const int max_len = code->max_len, min_len = code->min_len;
   if (max_len < 1 || max_len > 32 || min_len < 1 || min_len > max_len) {
+    if (tid == 0) latch_status(status, GHF_E_FORMAT);
+    return;
+  }
+  // The tables may come from anywhere (ghf_parse_header checks a header on the host; a caller's own ghf_code is not
+  // checked by anyone else).  A Huffman code over >= 2 symbols is COMPLETE: the lengths satisfy Kraft with equality
+  // (sum of 2^-len == 1), every length lies in [min_len, max_len], first codes fit their length and start positions
+  // stay inside symbol[].  Anything else would leave table entries without a code (length 0) and is refused.
+  if (tid == 0) {
+    kraft = 0;
+    bad = 0;
+  }
+  __syncthreads();
+  {
+    unsigned long long k = 0;
+    int b = 0;
+    for (int i = tid; i < GHF_NSYM; i += 256) {
+      const uint32_t l = code->length[i];
+      if (l) {
+        if ((int)l < min_len || (int)l > max_len) b = 1;
+        else k += 1ull << (32 - l);
+      }
+    }
+    if (tid >= min_len && tid <= max_len) {
+      const uint32_t fc = code->first_code[tid];
+      if ((tid < 32 && fc > (1u << tid)) || code->start_pos[tid] > (uint32_t)GHF_NSYM) b = 1;
+    }
+    if (k) atomicAdd(&kraft, k);
+    if (b) atomicOr(&bad, 1);
+  }
+  __syncthreads();
+  if (bad || kraft != (1ull << 32)) {
     if (tid == 0) latch_status(status, GHF_E_FORMAT);
     return;
   }

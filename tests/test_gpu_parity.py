@@ -466,3 +466,130 @@ def test_decode_prepare_is_single_use(env):
     assert int(nout.item()) == other.size and np.array_equal(back[: other.size].cpu().numpy(), other)
     ctx.index_free(idx2)
     ctx.index_free(idx)
+
+
+def test_histogram_in_pieces_and_stale_plan_cache(env):
+    """ghf_histogram_add over ragged pieces of a refilled buffer == the oracle's counts of the whole, and a plan on
+    that buffer afterwards prices what is in it NOW (the per-chunk counts of a piece are not kept)"""
+    ghf, ctx, torch = env
+    data = dg.text_bytes(1 << 20, seed=21)
+    cuts = [0, 1, 65537, 65537 + 262144, 700001, data.size]
+    buf = torch.empty(400000, dtype=torch.uint8, device="cuda")
+    hist = torch.zeros(ghf.NSYM, dtype=torch.int64, device="cuda")
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        buf[: hi - lo].copy_(to_dev(torch, data[lo:hi]))
+        ctx.histogram_add(buf, hist, n=hi - lo)
+    ctx.sync()
+    h = orc.histogram(data)
+    assert np.array_equal(hist.cpu().numpy(), np.asarray(h, dtype=np.int64))
+    d_code = ctx.build_code(hist)
+    lo, hi = cuts[-2], cuts[-1]  # same pointer and length as the last counted piece, other bytes
+    other = dg.uniform_bytes(hi - lo, seed=22)
+    buf[: hi - lo].copy_(to_dev(torch, other))
+    total = ctx.encode_plan(buf, d_code, n=hi - lo)
+    ctx.sync()
+    length = np.asarray(orc.build_code(h).length, dtype=np.int64)
+    assert int(total.item()) == int(length[other].sum())
+
+
+def test_events_order_two_contexts(env):
+    """ghf_event_record / wait / sync: a second context's stream consumes what the first one produces"""
+    import ctypes as C
+
+    ghf, ctx, torch = env
+    L = ghf.lib()
+    ctx2 = ghf.Context(0)
+    ev = C.c_void_p()
+    assert L.ghf_event_create(ctx.h, C.byref(ev)) == 0
+    try:
+        assert L.ghf_event_sync(ev) == 0  # never recorded: complete
+        data = dg.zipf_bytes(8 << 20, seed=31)
+        d_in = to_dev(torch, data)
+        hist = torch.zeros(ghf.NSYM, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.histogram(d_in, out=hist)
+        assert L.ghf_event_record(ctx.h, ev) == 0
+        assert L.ghf_event_wait(ctx2.h, ev) == 0
+        d_code = ctx2.build_code(hist)  # on ctx2's stream, behind the event
+        ctx2.sync()
+        assert L.ghf_event_sync(ev) == 0
+        assert ctx2.code_to_host(d_code).as_dict() == orc.build_code(orc.histogram(data)).as_dict()
+        assert L.ghf_event_record(None, ev) != 0 and L.ghf_event_wait(ctx.h, None) != 0
+    finally:
+        assert L.ghf_event_destroy(ev) == 0
+        ctx2.close()
+
+
+def test_decode_refuses_tables_that_are_not_a_complete_code(env):
+    """a caller's own ghf_code (not one ghf_parse_header vetted): lengths that break Kraft's equality, a length
+    outside [min_len, max_len], a first code that does not fit its length -- GHF_E_FORMAT, nothing decoded"""
+    ghf, ctx, torch = env
+    data = dg.zipf_bytes(100000, seed=41)
+    d_in, d_out, nb, d_code, idx = run_compress(ghf, ctx, torch, data)
+    good = ctx.code_to_host(d_code)
+
+    def attempt(mutate):
+        bad = ghf.Code.from_buffer_copy(bytes(good))
+        mutate(bad)
+        back = ctx.empty_u8(data.size + 64)
+        ctx.decode(d_out, nb, ctx.code_to_device(bad), idx, d_out=back)
+        with pytest.raises(ghf.GhfError) as e:
+            ctx.sync()
+        return e.value.status
+
+    used = [b for b in range(256) if good.length[b]]
+
+    def longer(c):
+        c.length[used[0]] += 1  # Kraft sum < 1: some bit patterns have no code
+
+    def shorter(c):
+        c.length[used[-1]] = c.min_len  # Kraft sum > 1
+
+    def outside(c):
+        c.length[used[1]] = c.max_len + 1
+
+    def wide_first_code(c):
+        c.first_code[c.min_len] = (1 << c.min_len) + 1
+
+    for m in (longer, shorter, outside, wide_first_code):
+        assert attempt(m) == 6, m.__name__
+    back, _ = ctx.decode(d_out, nb, d_code, idx)  # the untouched tables still decode
+    ctx.sync()
+    assert np.array_equal(back[: data.size].cpu().numpy(), data)
+    ctx.index_free(idx)
+
+
+@pytest.mark.parametrize("n", [(64 << 20) + 3, (160 << 20) + 1])
+def test_wide_codes_many_chunks_bit_exact(env, n):
+    """codes longer than 16 bits (K5's 64-bit table entries, two half-wave passes) over thousands of chunks: counts
+    fall off geometrically, so the lengths run from 1 to 25+ bits.  64 MiB = 4096 chunks of 16 KiB; 160 MiB = 5121
+    chunks of 32 KiB.  Bit-exact against the oracle, then the round trip with and without the side-car."""
+    ghf, ctx, torch = env
+    rng = np.random.default_rng(7)
+    counts = []
+    left = n
+    for k in range(40):
+        c = max(1, left // 2) if k < 39 and left > 1 else left
+        counts.append(c)
+        left -= c
+        if left == 0:
+            break
+    vals = np.repeat(np.arange(len(counts), dtype=np.uint8), counts)
+    # (a full permutation of 160 M elements is slow) scatter values all over the file instead: the rare, long-coded
+    # symbols then sit between the frequent ones in every chunk
+    data = vals.copy()
+    idx = rng.integers(0, n, size=n // 16, dtype=np.int64)
+    data[idx], data[idx[::-1]] = vals[idx[::-1]], vals[idx]
+    ref = orc.compress(data)
+    code = orc.build_code(orc.histogram(data))
+    assert code.max_len > 16
+    d_in, d_out, nb, d_code, ix = run_compress(ghf, ctx, torch, data)
+    assert nb == ref.size
+    assert sha(d_out[:nb].cpu().numpy()) == sha(ref)
+    back, _ = ctx.decode(d_out, nb, d_code, ix)
+    ctx.sync()
+    assert bool((back[:n] == d_in).all().item())
+    back2, nbytes = ctx.decode(d_out, nb, d_code, None, cap=n + 64)
+    ctx.sync()
+    assert int(nbytes.item()) == n and bool((back2[:n] == d_in).all().item())
+    ctx.index_free(ix)
