@@ -350,7 +350,7 @@ int ghf_histogram(ghf_ctx* c, const uint8_t* d_in, size_t n, uint64_t* d_hist) {
 int ghf_histogram_add(ghf_ctx* c, const uint8_t* d_in, size_t n, uint64_t* d_hist) { return histogram(c, d_in, n, d_hist, true); }
 
 int ghf_build_code_ex(ghf_ctx* c, const uint64_t* d_hist, ghf_code* d_code, unsigned flags) {
-  if (!c || !d_hist || !d_code || (flags & ~(unsigned)GHF_CODE_LIMIT)) return GHF_E_INVAL;
+  if (!c || !d_hist || !d_code || (flags & ~(unsigned)(GHF_CODE_LIMIT | GHF_EMPTY_OK))) return GHF_E_INVAL;
   GHF_HIP(c, hipSetDevice(c->device));
   launch_build_code(d_hist, d_code, c->d_status, flags, c->stream);
   GHF_HIP(c, hipGetLastError());
@@ -439,10 +439,24 @@ int ghf_compress(ghf_ctx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, size
 int ghf_compress_ex(ghf_ctx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes,
                     ghf_code* d_code, const ghf_index* index, unsigned code_flags) {
   if (!c || !d_out || (n && !d_in)) return GHF_E_INVAL;
-  if (n == 0) return fail(c, GHF_E_EMPTY, "empty input is undefined in the reference; refused");
+  if (n == 0 && !(code_flags & GHF_EMPTY_OK)) return fail(c, GHF_E_EMPTY, "empty input is undefined in the reference; refused");
   if (!aligned16(d_out)) return fail(c, GHF_E_INVAL, "d_out must be 16-byte aligned");
   ghf_code* code = d_code ? d_code : c->d_code;
   int rc;
+  if (n == 0) {
+    // GHF_EMPTY_OK (include/ghf.h): header of the one-symbol code + the byte 0x7F.  No K4/K5: there is nothing to pack.
+    const size_t hdr = ghf_header_bytes(1);
+    if (cap < hdr + 1) return fail(c, GHF_E_CAP, "ghf_compress: capacity below the 1049 bytes of the empty stream");
+    if ((rc = ghf_histogram(c, d_in, 0, c->d_hist))) return rc;
+    if ((rc = ghf_build_code_ex(c, c->d_hist, code, code_flags))) return rc;
+    if ((rc = ghf_write_header(c, code, d_out, cap))) return rc;
+    GHF_HIP(c, hipMemsetAsync(d_out + hdr, 0x7F, 1, c->stream));
+    if (d_out_bytes) {
+      launch_store_u64(d_out_bytes, nullptr, hdr + 1, c->stream);
+      GHF_HIP(c, hipGetLastError());
+    }
+    return GHF_OK;
+  }
   if ((rc = ghf_histogram(c, d_in, n, c->d_hist))) return rc;   // compressor.h:63
   if ((rc = ghf_build_code_ex(c, c->d_hist, code, code_flags))) return rc;  // compressor.h:64
   if ((rc = ghf_encode_plan(c, d_in, n, code, c->d_u64))) return rc;
@@ -522,7 +536,15 @@ int ghf_parse_header(const uint8_t* h, size_t n, ghf_code* code, size_t* header_
       return GHF_E_FORMAT;
     }
   }
-  if (used < 2 || !seen[GHF_NSYM - 1]) return GHF_E_FORMAT;
+  if (!seen[GHF_NSYM - 1]) return GHF_E_FORMAT;
+  // one symbol only: the empty stream of GHF_EMPTY_OK -- the end mark alone, code "0" (not a complete code: checked here, not below)
+  if (used == 1) {
+    if (max_len != 1 || code->first_code[1] != 0 || code->start_pos[1] != 0) return GHF_E_FORMAT;
+    code->length[GHF_NSYM - 1] = 1;
+    code->codeword[GHF_NSYM - 1] = 0;
+    if (header_bytes) *header_bytes = 1040 + 8;
+    return GHF_OK;
+  }
   // rebuild per-symbol lengths/codewords; the code must be the canonical complete prefix code
   uint64_t kraft = 0;  // in units of 2^-32
   for (uint32_t len = min_len; len <= max_len; ++len) {
@@ -781,6 +803,13 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
     }
     c->fidx_stream = nullptr;  // single use: the buffer may be rewritten afterwards
     index = &c->fidx;
+  }
+  if (index->n_symbols == 0) {  // the end mark comes first (GHF_EMPTY_OK's stream, or a shard that holds nothing): no K7
+    if (d_out_bytes) {
+      launch_store_u64(d_out_bytes, nullptr, 0, c->stream);
+      GHF_HIP(c, hipGetLastError());
+    }
+    return GHF_OK;
   }
   if (!index->d_chunk_bit || !index->d_seg_bit || index->seg_symbols != (uint32_t)kSegSymbols ||
       index->chunk_symbols != (uint32_t)kBlockSymbols || index->n_segs != (index->n_symbols + kSegSymbols - 1) / kSegSymbols ||

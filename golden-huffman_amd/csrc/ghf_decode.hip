@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void k_build_decode_tables(const ghf_code* __r
     if (b) atomicOr(&bad, 1);
   }
   __syncthreads();
-  if (bad || kraft != (1ull << 32)) {
+  const bool lone_end_mark = max_len == 1 && kraft == (1ull << 31) && code->length[GHF_NSYM - 1] == 1;  // GHF_EMPTY_OK's stream
+  if (bad || (kraft != (1ull << 32) && !lone_end_mark)) {
     if (tid == 0) latch_status(status, GHF_E_FORMAT);
     return;
   }

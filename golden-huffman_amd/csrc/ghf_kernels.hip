@@ -451,7 +451,7 @@ __device__ void limit_lengths_32(LimitLds& Q, const uint32_t (&len)[5], int lane
 struct NoLimitLds {};
 template <bool LIMIT>
 __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __restrict__ hist, ghf_code* __restrict__ out,
-                                                   int* __restrict__ status) {
+                                                   int* __restrict__ status, uint32_t empty_ok) {
   __shared__ HeapLds heap;
   __shared__ typename std::conditional<LIMIT, LimitLds, NoLimitLds>::type Q;
   // one latency-bound wave among thousands of streaming ones (the other kernels of a pipelined caller share its CU):
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
     }
   }
   __syncthreads();
-  if (s_ndata == 0) {  // empty input: undefined in the reference
+  if (s_ndata == 0 && !empty_ok) {  // empty input: undefined in the reference
     if (lane == 0) latch_status(status, GHF_E_EMPTY);
     return;
   }
@@ -534,6 +534,8 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
     }
     if (!__ballot(any)) break;
   }
+  // GHF_EMPTY_OK: the lone end mark (no merge happened, its depth is 0) gets the one-bit code "0" -- our definition
+  if (s_ndata == 0 && lane == 0) len[4] = 1;
   uint32_t mx = 0;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
@@ -621,9 +623,11 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
 
 void launch_build_code(const uint64_t* d_hist, ghf_code* d_code, int* d_status, uint32_t flags, hipStream_t s) {
   if (flags & GHF_CODE_LIMIT)
-    hipLaunchKernelGGL(k_build_code<true>, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(d_hist), d_code, d_status);
+    hipLaunchKernelGGL(k_build_code<true>, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(d_hist), d_code, d_status,
+                       flags & GHF_EMPTY_OK);
   else
-    hipLaunchKernelGGL(k_build_code<false>, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(d_hist), d_code, d_status);
+    hipLaunchKernelGGL(k_build_code<false>, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned long long*>(d_hist), d_code, d_status,
+                       flags & GHF_EMPTY_OK);
 }
 
 // ------------------------------------------------------------------------------------------------

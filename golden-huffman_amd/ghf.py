@@ -10,6 +10,7 @@ EMIT_REBASE = 2
 EMIT_HEADER = 4
 INDEX_NO_END_MARK = 1
 CODE_LIMIT = 1
+EMPTY_OK = 2  # opt-in: n == 0 -> header of the one-symbol code + 0x7F (builder's definition, parity unpinned)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libghf.so")

@@ -252,6 +252,14 @@ size_t ghf_shard_bound(size_t n); /* header + 4 n (32 bits per symbol) + end mar
  * default output stays bit-exact.
  * ------------------------------------------------------------------------------------------------ */
 #define GHF_CODE_LIMIT 1u
+/* Opt-in, second half of N4: the EMPTY input.  The reference is undefined there (its merge loop, include/
+ * canonical_huff_encoder.cc:309-343, runs n - 1 = 0 times over the lone end mark and leaves every length 0).  With
+ * GHF_EMPTY_OK, ghf_build_code_ex gives the end mark the one-bit code "0" (min_len = max_len = 1) and ghf_compress_ex
+ * (n == 0) writes the 1048-byte header of that code followed by the byte 0x7F (the end mark, then 1-bits up to the
+ * byte, as flush_bits pads): 1049 bytes that ghf_parse_header accepts and ghf_decode turns back into nothing.
+ * This is the builder's own definition -- PARITY UNPINNED: no reference output exists to compare with.  The staged
+ * calls (ghf_encode_plan / ghf_encode_emit) keep refusing n == 0. */
+#define GHF_EMPTY_OK 2u
 int ghf_build_code_ex(ghf_ctx* ctx, const uint64_t* d_hist, ghf_code* d_code, unsigned flags);
 int ghf_compress_ex(ghf_ctx* ctx, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes,
                     ghf_code* d_code, const ghf_index* index, unsigned code_flags);

@@ -205,6 +205,23 @@ def compress_limited(data, limit=32):
     return out[: n.value].copy()
 
 
+def compress_empty():
+    """SURVEY 8(f) N4, second half: the opt-in definition of the EMPTY input (GHF_EMPTY_OK, include/ghf.h).  PARITY
+    UNPINNED -- the reference is undefined at n == 0 (include/canonical_huff_encoder.cc:309-343: no merge happens, every
+    length stays 0), so this restates the builder's own definition, not the reference: the end mark alone with the
+    one-bit code "0", its header as write_encode_info (canonical_huff_encoder.cc:210-242) would lay it out, then the
+    byte 0x7F = the end mark followed by the 1-bits flush_bits pads with (utils/include/buffer.h:290-295)."""
+    c = OrcCode()
+    for i in range(NSYM):
+        c.symbol[i] = 0xFFFFFFFF
+    c.symbol[0] = NSYM - 1
+    c.length[NSYM - 1] = 1
+    c.min_len = c.max_len = 1
+    c.first_code[1] = 0
+    c.start_pos[1] = 0
+    return np.concatenate([header_bytes(c), np.array([0x7F], dtype=np.uint8)])
+
+
 # ------------------------------------------------------------------ SURVEY 8(f) N3: .crs (NormalHuffEncoder)
 def crs_tree(hist256):
     h = np.ascontiguousarray(hist256[:256], dtype=np.int64)

@@ -85,6 +85,25 @@ def test_parse_header_rejects_garbage(ghf, golden):
 
 
 # ---------------------------------------------------------------- .crs host-side entry points
+def test_empty_stream_definition_is_accepted_by_the_host_parser(ghf):
+    """SURVEY 8(f) N4, opt-in GHF_EMPTY_OK -- PARITY UNPINNED (the reference is undefined at n == 0): the oracle's
+    restatement of OUR definition (header of the lone end mark's one-bit code + 0x7F) parses, and the oracle's own
+    decoder loop (the reference's, which stops at the end mark) reads it back as nothing"""
+    from oracle import oracle as orc
+
+    s = orc.compress_empty()
+    assert s.size == 1049 and s[-1] == 0x7F
+    code, hs = ghf.parse_header(s)
+    assert hs == 1048 and code.min_len == 1 and code.max_len == 1
+    assert code.length[256] == 1 and code.codeword[256] == 0 and sum(code.length) == 1
+    assert orc.decompress(s).size == 0
+    # one symbol that is NOT the end mark stays a format error
+    bad = s.copy()
+    bad[4:8] = [0, 0, 0, 65]
+    with pytest.raises(ghf.GhfError):
+        ghf.parse_header(bad)
+
+
 def test_crs_struct_layout(ghf):
     assert C.sizeof(ghf.Tree) == 2 * 256 * 2 + 4 * 4 + 1024
 

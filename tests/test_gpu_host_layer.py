@@ -189,6 +189,20 @@ def test_pipeline_multi_gib_file_bit_exact_and_rate(tool, tmp_path):
                 json.dump(rep, fh)
 
 
+def test_empty_file_opt_in_through_the_host_layer(tool, tmp_path):
+    """GHF_EMPTY_OK=1 (or set_allow_empty): the empty file becomes the 1049-byte stream of include/ghf.h's definition
+    (parity unpinned -- the reference is undefined there) and comes back as an empty file; the default stays a refusal"""
+    f = tmp_path / "empty.bin"
+    f.write_bytes(b"")
+    assert subprocess.run([tool, str(f), "3"], capture_output=True, timeout=60).returncode == 1
+    assert subprocess.run([tool, str(f), "3"], timeout=60, env=_env(GHF_EMPTY_OK=1)).returncode == 0
+    crs = np.fromfile(str(f) + ".crs2", dtype=np.uint8)
+    assert np.array_equal(crs, orc.compress_empty())
+    for mode in ("4", "5", "6"):
+        assert subprocess.run([tool, str(f) + ".crs2", mode], timeout=60).returncode == 0
+        assert os.path.getsize(str(f) + ".crs2.de") == 0
+
+
 def test_streaming_stager_multi_piece_file(tool, tmp_path):
     """a 70 MiB file = five 16 MiB pieces each way through the pipeline (reader/writer threads, pinned rings, three streams)"""
     import datagen as dg

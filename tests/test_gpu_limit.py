@@ -93,3 +93,37 @@ def test_whole_stream_beyond_the_reference_limit(env, k):
             crs.tofile(f)
             orc.ref_run(["d", f, f + ".de"], timeout=300)
             assert np.array_equal(np.fromfile(f + ".de", dtype=np.uint8), data)
+
+
+def test_empty_input_opt_in(env):
+    """the other half of N4: n == 0 stays refused by default (undefined in the reference); with GHF_EMPTY_OK it is the
+    1049 bytes of the oracle's restatement of our definition (PARITY UNPINNED: no reference output exists), which
+    K6 + K7 decode back to nothing.  The flag changes nothing for inputs that are not empty."""
+    ghf, ctx, torch = env
+    nothing = ctx.empty_u8(16)
+    with pytest.raises(ghf.GhfError) as e:
+        ctx.compress(nothing, n=0)
+    assert e.value.status == 3
+    d_out, nbytes, d_code = ctx.compress(nothing, n=0, code_flags=ghf.EMPTY_OK)
+    ctx.sync()
+    ref = orc.compress_empty()
+    nb = int(nbytes.item())
+    assert nb == ref.size == 1049 and np.array_equal(d_out[:nb].cpu().numpy(), ref)
+    code = ctx.code_to_host(d_code)
+    assert code.min_len == 1 and code.max_len == 1 and code.length[256] == 1 and sum(code.length) == 1
+    # no side-car: header parsed on the host, K6 finds the end mark first, nothing for K7 to do
+    hcode, hs = ghf.parse_header(d_out[:nb].cpu().numpy())
+    back, n_out = ctx.decode(d_out, nb, ctx.code_to_device(hcode), None, cap=64)
+    ctx.sync()
+    assert int(n_out.item()) == 0
+    # the staged calls keep refusing, the histogram alone is fine (only the end mark counts)
+    h = ctx.histogram(nothing, n=0)
+    ctx.build_code(h)
+    with pytest.raises(ghf.GhfError) as e:
+        ctx.sync()
+    assert e.value.status == 3
+    data = dg.zipf_bytes(50000, seed=12)
+    d_in = torch.from_numpy(data).cuda()
+    a, na, _ = ctx.compress(d_in, code_flags=ghf.EMPTY_OK)
+    ctx.sync()
+    assert np.array_equal(a[: int(na.item())].cpu().numpy(), orc.compress(data))
