@@ -3,12 +3,12 @@
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W [--mib 4096]
+         bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one synthetic buffer per rank: histogram -> one-wave code
 build -> bit-length scan -> bit-pack with header (encode), then table decode of the result.  The input is
 resident in HBM before the timed region.  N=1: BASELINE config 2 (256 MiB uniform-random bytes).
-N>1: every rank holds a shard of one N x (--mib) MiB stream (weak scaling; --mib 4096 = BASELINE config 4);
+N>1: every rank holds a 4 GiB shard of one N x 4 GiB stream (weak scaling; N = 8 is BASELINE config 4: 32 GiB);
 one global code via an RCCL all-reduce of the 256-bin histogram and an all-gather of the per-rank bit totals.
 
 Rank 0 prints ONE JSON line.  `value` = input GB (1e9 B) pushed through encode+decode per second by the
@@ -34,14 +34,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mib", type=int, default=256, help="input MiB per GPU")
+    ap.add_argument("--mib", type=int, default=None, help="input MiB per GPU (default: 256 at N=1 = config 2, 4096 at N>1 = config 4's shard)")
     ap.add_argument("--kind", default="uniform", choices=["uniform", "zipf", "sym16"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 control flow with several ranks on ONE GPU (collectives staged via host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the 4 GiB configs block (N=1)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.mib is None:
+        args.mib = 256 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 4096
+    return args
 
 
 def cpu_baseline(data_host, kind):
