@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
 #pragma unroll
     for (int k = 0; k < kDecVec; ++k) {  // lanes behind the span re-read the span's first bytes (an L2 hit)
       const uint32_t o = (uint32_t)k * 1024u + (uint32_t)lane * 16u;
-      R[k] = *reinterpret_cast<const uint4*>(base + (o + 16u <= lim ? o : 0u));
+      R[k] = load_stream(base + (o + 16u <= lim ? o : 0u));  // read once: not worth a line of the Infinity Cache
     }
   };
 
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
           for (int r = 0; r < 4; ++r) {
             const uint32_t sl = (uint32_t)r * 16 + ((uint32_t)ln >> 2);  // the ln whose row holds my piece
             const uint32_t piece = ((uint32_t)ln & 3u) ^ ((sl >> 2) & 3u);
-            *reinterpret_cast<uint4*>(og + r * 1024) = *reinterpret_cast<const uint4*>(tile + sl * 16 + piece * 4);
+            store_stream(og + r * 1024, *reinterpret_cast<const uint4*>(tile + sl * 16 + piece * 4));
           }
         } else if (VAR == 4) {
           acc = dec_hot_long<2>(L, lin, la0, T1, lut_bits, max_len, cur.pos, P.out + sym0, used);

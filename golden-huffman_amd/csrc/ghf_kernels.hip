@@ -86,17 +86,19 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
       if (c >= nfullchunks) c = nfullchunks - 1;  // past the end: redundant, harmless loads
       return reinterpret_cast<const uint4*>(in + (uint64_t)c * chunk) + (uint64_t)j * kHistThreads + tid;
     };
-    uint4 A = *vptr(cur, 0), B = *vptr(cur, 1);
+    // non-temporal loads: the input streams past the Infinity Cache instead of through it (4 GiB: 0.79 -> 0.69 ms, i.e.
+    // 6.2 TB/s of reads; nothing changes at 256 MiB, where the pipelined neighbours' write-backs set the pace)
+    uint4 A = load_stream(vptr(cur, 0)), B = load_stream(vptr(cur, 1));
     while (cur < nfullchunks) {
       uint32_t t_next = 0;
       if (tid == 0) t_next = draw();  // the chunk after next; the atomic returns long before it is needed
       for (uint32_t j = 0; j < V; j += 4) {
-        const uint4 C = *vptr(cur, j + 2), D = *vptr(cur, j + 3);
+        const uint4 C = load_stream(vptr(cur, j + 2)), D = load_stream(vptr(cur, j + 3));
         hist_vec(lh, rep, A);
         hist_vec(lh, rep, B);
         const bool more = j + 4 < V;
-        A = *vptr(more ? cur : nxt, more ? j + 4 : 0);
-        B = *vptr(more ? cur : nxt, more ? j + 5 : 1);
+        A = load_stream(vptr(more ? cur : nxt, more ? j + 4 : 0));
+        B = load_stream(vptr(more ? cur : nxt, more ? j + 5 : 1));
         hist_vec(lh, rep, C);
         hist_vec(lh, rep, D);
       }

@@ -1073,7 +1073,9 @@ class HipCanonicalHuffDecoder<unsigned char> {
     // Where the decoded bytes wait for the file.  Making the output file's pages is the slowest stage (20 GB/s, and no
     // copy into the file may run meanwhile), and how many are needed is only known at the end mark.  So: the first
     // piece tells the ratio; if the estimated output fits GHF_RESIDENT_BYTES it ALL stays in HBM (`whole`) while a pool
-    // thread makes 97 % of the estimated pages, and it leaves in one sweep at the end, when the exact size is known.
+    // thread makes 97 % of the estimated pages, and it leaves in one sweep at the end, when the exact size is known
+    // (sweeping the pieces whose pages exist while the rest is still being made was tried: page-making and copying
+    // into the same file get in each other's way, 4 GiB took 480-700 ms instead of 410-470).
     // Otherwise (or once `whole` is full) a piece leaves as soon as it is decoded, through the kOut-deep ring.
     struct Held {
       const uint8_t* d;
