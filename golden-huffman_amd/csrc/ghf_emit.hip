@@ -30,7 +30,6 @@ struct WaveOut {
   uint4* out_units;    // output as 16-byte units
   uint64_t unit_base;  // unit index (in out) of staging unit 0
   uint32_t carry;      // valid bits at the front of the staging area (< 128)
-  bool stream;         // store the units with the non-temporal hint (wave-uniform)
 };
 
 // OR the `len` low bits of q (len <= 64, q < 2^len) into the bit string at bit position p (MSB first inside every word)
@@ -80,8 +79,7 @@ __device__ __forceinline__ uint32_t emit_items(WaveOut& W, const uint64_t (&q)[N
       uint4 v = *su;
       *su = make_uint4(0, 0, 0, 0);
       v.x = bswap32(v.x); v.y = bswap32(v.y); v.z = bswap32(v.z); v.w = bswap32(v.w);
-      if (W.stream) store_stream(&W.out_units[W.unit_base + j], v);
-      else W.out_units[W.unit_base + j] = v;
+      W.out_units[W.unit_base + j] = v;  // (a non-temporal hint here: no gain up to 1 GiB, 7 % slower at 4 GiB -- K7 reads this soon)
     }
   }
   wave_sync();
@@ -229,10 +227,6 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
   W.st = st;
   W.bit0 = (uint32_t)(st - flat) * 32u;
   W.out_units = reinterpret_cast<uint4*>(P.out);
-  // An output about the size of the 256 MiB Infinity Cache would sit there as dirty lines that the next kernel's reads
-  // must evict first; streamed past the cache it does not (pipelined 256 MiB bench: K1 and K7 gain more than K5 loses).
-  // Large outputs never fit anyway, and there the hinted partial-wave stores cost K5 7 % (4 GiB: 1.94 -> 2.07 ms).
-  W.stream = P.n <= (1ull << 30);
   W.unit_base = (Pc >> 7) - (G.origin_byte >> 4);
   W.carry = (uint32_t)(Pc & 127u);
   for (int i = lane; i < kStageWords / 4; i += 64) reinterpret_cast<uint4*>(st)[i] = make_uint4(0, 0, 0, 0);
