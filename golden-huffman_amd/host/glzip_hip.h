@@ -501,7 +501,7 @@ class Pipe {
   // and page-making is the slowest stage of the output side.  cancel_presize() before the file is closed.
   void presize(int fd, size_t bytes) {
     cancel_presize();
-    if (!wants_map(bytes)) return;
+    if (!wants_map(bytes) || env_bytes("GHF_IO_THREADS", 12) < 3) return;  // (it would sit in front of the reads in the queue)
     pre_fd_ = fd;
     pre_done_ = 0;
     pre_stop_ = false;
