@@ -850,7 +850,29 @@ __global__ __launch_bounds__(256) void k_chunk_bits_direct(const uint8_t* __rest
     const uint64_t base = (uint64_t)c * chunk;
     const uint64_t len = (n - base < chunk) ? (n - base) : chunk;
     unsigned long long b = 0;
-    for (uint64_t i = lane; i < len; i += 64) b += ll[in[base + i]];
+    // 16 bytes per lane and load where the chunk is 16-byte aligned (every piece of a file, every shard: this is the K4 of
+    // the callers that have no per-chunk counts from K1), single bytes for a ragged head and tail
+    const uint8_t* p = in + base;
+    uint64_t head = (16u - (uint32_t)((uintptr_t)p & 15u)) & 15u;
+    if (head > len) head = len;
+    if ((uint64_t)lane < head) b += ll[p[lane]];
+    const uint4* pv = reinterpret_cast<const uint4*>(p + head);
+    const uint64_t nvec = (len - head) >> 4;
+    uint32_t acc = 0;
+    for (uint64_t i = lane; i < nvec; i += 64) {
+      const uint4 v = pv[i];  // (K5 reads the same bytes next: let them stay in the caches)
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        acc += ll[w[k] & 0xFFu] + ll[(w[k] >> 8) & 0xFFu] + ll[(w[k] >> 16) & 0xFFu] + ll[w[k] >> 24];
+      if ((i >> 6) % 4096u == 4095u) {  // (64 lanes x 16 symbols x 255 bits per round: far from 2^32 in 4096 rounds)
+        b += acc;
+        acc = 0;
+      }
+    }
+    b += acc;
+    const uint64_t tail0 = head + (nvec << 4);
+    if (tail0 + (uint64_t)lane < len) b += ll[p[tail0 + lane]];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) b += __shfl_xor(b, d, 64);
     if (lane == 0) bits[c] = b;
