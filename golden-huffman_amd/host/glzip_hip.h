@@ -566,16 +566,16 @@ class Pipe {
     Jobs job;               // the last read into / writes from buf
   };
   typedef std::vector<Slot> Ring;
-  void ensure_ring(Ring& r, size_t bytes) {
-    if (r.empty()) r = Ring(kSlots);
-    for (size_t i = 0; i < r.size(); ++i)
-      if (r[i].buf.n < bytes) r[i].buf.alloc(run_s_, bytes);
+  void ensure_ring(Ring& r, size_t bytes) {  // (a slot is pinned when it is first taken: the first pieces of a process's
+    if (r.empty()) r = Ring(kSlots);          //  first file do not wait for 192 MiB of hipHostMalloc)
+    slot_bytes_ = bytes > slot_bytes_ ? bytes : slot_bytes_;
   }
   int acquire(Ring& r, size_t& next) {  // oldest slot of the ring, once its last job and copy are over
     StepSum::Scope t(t_slot_);
     const int si = (int)(next++ % r.size());
     r[si].job.get();
     r[si].copied.sync();
+    if (r[si].buf.n < slot_bytes_) r[si].buf.alloc(run_s_, slot_bytes_);
     return si;
   }
   struct Landing {  // a segment on its way from the device into the pinned ring
@@ -672,7 +672,7 @@ class Pipe {
   Session in_s_, run_s_, out_s_;
   size_t piece_;
   Ring in_ring_, out_ring_;
-  size_t in_next_, out_next_;
+  size_t in_next_, out_next_, slot_bytes_ = 0;
   int fd_;
   size_t base_, total_, extra_, next_read_, next_feed_;
   std::deque<int> pend_;  // slots of the reads that were started and not fed yet, in piece order
