@@ -115,7 +115,7 @@ uint64_t* ghf_api_totals(ghf_ctx* c, int world) {
 
 extern "C" {
 
-int ghf_version(void) { return 200; }
+int ghf_version(void) { return 210; }  // 2.1: events, ghf_histogram_add, GHF_EMPTY_OK, table validation
 
 const char* ghf_status_string(int s) {
   switch (s) {

@@ -181,6 +181,11 @@ int ghf_parse_header(const uint8_t* h_stream, size_t n, ghf_code* code, size_t* 
  * and index the side-car that call filled: the decode is then block-parallel (length-indexed canonical
  * table in LDS).  Without one (index == NULL, e.g. a .crs2 written by the reference; d_stream must then
  * be a whole .crs2 image) the index is first rebuilt on the GPU from the bit stream.
+ * d_code may come from anywhere: before anything is decoded the tables are checked on the device to be a
+ * complete prefix code (Kraft equality, lengths within [min_len, max_len], first codes that fit their length,
+ * start positions inside symbol[]; the one-symbol code of GHF_EMPTY_OK is the exception) -- if not,
+ * GHF_E_FORMAT is latched and nothing is written.  Every 64-symbol segment's end is checked against the index
+ * (GHF_E_CORRUPT).  A stream whose first code is the end mark decodes to nothing without launching K7.
  * d_out_bytes: device u64 = decoded size. */
 int ghf_decode(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, const ghf_code* d_code,
                const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes);
