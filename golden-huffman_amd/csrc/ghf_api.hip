@@ -959,6 +959,33 @@ int ghf_crs_decoded_size(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
   return GHF_OK;
 }
 
+int ghf_crs_sync_piece(ghf_ctx* c, const uint8_t* d_piece, size_t piece_bytes, uint32_t first_bit, uint64_t end_bit,
+                       const ghf_tree* d_tree, uint64_t* landing, uint64_t* n_symbols) {
+  if (!c || !d_piece || !d_tree || !landing || !n_symbols) return GHF_E_INVAL;
+  if (!aligned16(d_piece)) return fail(c, GHF_E_INVAL, "d_piece must be 16-byte aligned");
+  if (first_bit >= 512 || end_bit > (uint64_t)piece_bytes * 8 || first_bit > end_bit) return fail(c, GHF_E_INVAL, "ghf_crs_sync_piece: bad first_bit / end_bit");
+  GHF_HIP(c, hipSetDevice(c->device));
+  launch_crs_decode_tables(d_tree, c->d_dt, c->d_status, c->stream);
+  c->dt_code = nullptr;
+  c->fidx_stream = nullptr;
+  *landing = 0;
+  *n_symbols = 0;
+  if (end_bit == 0) {  // nothing of this piece is its own
+    c->fidx.n_symbols = 0;
+    c->fidx.n_segs = 0;
+    c->fidx.n_chunks = 0;
+    c->fidx_stream = d_piece;
+    c->fidx_bytes = piece_bytes;
+    return GHF_OK;
+  }
+  int bad = 0;  // with the tree's tables "end mark" can only mean: bits that are no code
+  const int rc = rebuild_index_at(c, d_piece, piece_bytes, 0, end_bit, 2, (size_t)-1, first_bit, landing, &bad);
+  if (rc) return rc;
+  if (bad) return fail(c, GHF_E_CORRUPT, "the .crs body holds bits that are no code");
+  *n_symbols = c->fidx.n_symbols;
+  return GHF_OK;
+}
+
 int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int left_bits, const ghf_tree* d_tree,
                    const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes) {
   if (!c || !d_stream || !d_tree || !d_out) return GHF_E_INVAL;
@@ -967,20 +994,24 @@ int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int
   launch_crs_decode_tables(d_tree, c->d_dt, c->d_status, c->stream);
   c->dt_code = nullptr;
   if (!index) {
-    size_t hdr;
-    uint64_t end_bit;
-    int rc = crs_geometry(c, d_tree, stream_bytes, left_bits, &hdr, &end_bit);
-    if (rc) return rc;
-    if (end_bit == (uint64_t)hdr * 8) {
-      if (d_out_bytes) launch_store_u64(d_out_bytes, nullptr, 0, c->stream);
-      return GHF_OK;
-    }
-    if (c->fidx_stream != d_stream || c->fidx_bytes != stream_bytes) {
+    if (c->fidx_stream != d_stream || c->fidx_bytes != stream_bytes) {  // else: ghf_crs_decoded_size / ghf_crs_sync_piece did it
+      size_t hdr;
+      uint64_t end_bit;
+      int rc = crs_geometry(c, d_tree, stream_bytes, left_bits, &hdr, &end_bit);
+      if (rc) return rc;
+      if (end_bit == (uint64_t)hdr * 8) {
+        if (d_out_bytes) launch_store_u64(d_out_bytes, nullptr, 0, c->stream);
+        return GHF_OK;
+      }
       rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, 1, cap);
       if (rc) return rc;
     }
     c->fidx_stream = nullptr;
     index = &c->fidx;
+    if (index->n_symbols == 0) {
+      if (d_out_bytes) launch_store_u64(d_out_bytes, nullptr, 0, c->stream);
+      return GHF_OK;
+    }
   }
   if (!index->d_chunk_bit || !index->d_seg_bit || index->seg_symbols != (uint32_t)kSegSymbols ||
       index->chunk_symbols != (uint32_t)kBlockSymbols || index->n_segs != (index->n_symbols + kSegSymbols - 1) / kSegSymbols ||

@@ -105,6 +105,7 @@ EXPORTS = [
     "ghf_comm_unique_id", "ghf_comm_init_rank", "ghf_comm_destroy", "ghf_comm_world", "ghf_rccl_version",
     "ghf_comm_allreduce_hist", "ghf_comm_allgather_total", "ghf_encode_sharded", "ghf_shard_bound",
     "ghf_event_create", "ghf_event_destroy", "ghf_event_record", "ghf_event_wait", "ghf_event_sync", "ghf_histogram_add",
+    "ghf_crs_sync_piece",
 ]
 COMM_ID_BYTES = 128
 
@@ -179,6 +180,7 @@ def lib():
     L.ghf_crs_parse_header.argtypes = [vp, sz, C.POINTER(Tree), C.POINTER(sz)]
     L.ghf_crs_decode.argtypes = [vp, vp, sz, i32, vp, C.POINTER(Index), vp, sz, vp]
     L.ghf_crs_decoded_size.argtypes = [vp, vp, sz, i32, vp, C.POINTER(u64)]
+    L.ghf_crs_sync_piece.argtypes = [vp, vp, sz, C.c_uint32, u64, vp, C.POINTER(u64), C.POINTER(u64)]
     L.ghf_comm_unique_id.argtypes = [C.c_char_p]
     L.ghf_comm_init_rank.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(vp)]
     L.ghf_comm_destroy.argtypes = [vp]
@@ -496,6 +498,13 @@ class Context:
         self._chk(self.L.ghf_crs_decoded_size(self.h, d_stream.data_ptr(), stream_bytes, left_bits, d_tree.data_ptr(), C.byref(n)),
                   "ghf_crs_decoded_size")
         return n.value
+
+    def crs_sync_piece(self, d_piece, piece_bytes, first_bit, end_bit, d_tree):
+        """one piece of a .crs body (no end mark in this format): -> (landing, n_symbols)"""
+        landing, n = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.L.ghf_crs_sync_piece(self.h, d_piece.data_ptr(), piece_bytes, first_bit, end_bit, d_tree.data_ptr(),
+                                            C.byref(landing), C.byref(n)), "ghf_crs_sync_piece")
+        return landing.value, n.value
 
     def crs_decode(self, d_stream, stream_bytes, left_bits, d_tree, index=None, d_out=None, cap=None, nbytes=None):
         """d_stream: the .crs image with the stored last byte appended behind the body when left_bits != 0."""

@@ -317,6 +317,14 @@ int ghf_crs_decode(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, i
                    const ghf_index* index, uint8_t* d_out, size_t cap, uint64_t* d_out_bytes);
 int ghf_crs_decoded_size(ghf_ctx* ctx, const uint8_t* d_stream, size_t stream_bytes, int left_bits, const ghf_tree* d_tree,
                          uint64_t* n_out);
+/* A .crs body in pieces (the file pipeline of the host layer; the format has no sync points and no end mark either):
+ * as ghf_sync_piece, with the tree instead of canonical tables.  d_piece: the piece's own bytes + >= 8 bytes of
+ * look-ahead (for the last piece: the stored last byte, then zeros); end_bit = 8 * own bytes, for the last piece minus
+ * left_bits of the stored byte that was appended.  landing = where the next piece's first code begins (the last piece
+ * must land on 0: the stream ends on a code boundary); n_symbols = codes that start in [first_bit, end_bit).
+ * ghf_crs_decode(d_piece, piece_bytes, 0, d_tree, NULL, ...) then decodes the piece with the side-car this call rebuilt. */
+int ghf_crs_sync_piece(ghf_ctx* ctx, const uint8_t* d_piece, size_t piece_bytes, uint32_t first_bit, uint64_t end_bit,
+                       const ghf_tree* d_tree, uint64_t* landing, uint64_t* n_symbols);
 
 #ifdef __cplusplus
 }

@@ -188,3 +188,42 @@ def test_crs_errors(env):
         ctx.sync()
     assert e.value.status == 7
     ctx.index_free(idx)
+
+
+@pytest.mark.parametrize("kind,n,piece", [("text", 1 << 20, 65536), ("zipf", (3 << 20) + 17, 1 << 18), ("uniform", 300001, 4096), ("sym16", 70000, 1000)])
+def test_crs_body_in_pieces(env, kind, n, piece):
+    """ghf_crs_sync_piece + ghf_crs_decode(index = NULL) piece by piece (what the host layer's file pipeline does with a
+    .crs): every piece gets the exact first bit from the landing of the one before; the last piece carries the stored
+    last byte and must land on a code boundary; the pieces' outputs concatenate to the input."""
+    ghf, ctx, torch = env
+    data = dg.make(kind, n, seed=5)
+    crs = orc.crs_compress(data)
+    htree, tb = ghf.crs_parse_header(crs)
+    d_tree = ctx.tree_to_device(htree)
+    left, last_byte = int(crs[tb]), int(crs[tb + 1])
+    body = crs[tb + 2 :]
+    out = []
+    first = 0
+    npieces = (body.size + piece - 1) // piece
+    for k in range(npieces):
+        lo, hi = k * piece, min(body.size, (k + 1) * piece)
+        own = hi - lo
+        buf = np.zeros(((own + 16 + 15) // 16) * 16 + 16, dtype=np.uint8)
+        avail = min(body.size, hi + 16) - lo
+        buf[:avail] = body[lo : lo + avail]
+        end_bit = 8 * own
+        if k == npieces - 1 and left:
+            buf[own] = last_byte
+            end_bit += 8 - left
+        d_piece = to_dev(torch, buf)
+        landing, nsym = ctx.crs_sync_piece(d_piece, buf.size, first, end_bit, d_tree)
+        if nsym:
+            dec, nb = ctx.crs_decode(d_piece, buf.size, 0, d_tree, None, cap=nsym + 64)
+            ctx.sync()
+            assert int(nb.item()) == nsym
+            out.append(dec[:nsym].cpu().numpy())
+        if k == npieces - 1:
+            assert landing == 0
+        first = landing
+    got = np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
+    assert got.size == data.size and np.array_equal(got, data)
