@@ -309,7 +309,7 @@ __device__ __forceinline__ uint32_t dec_long_entry(const LT& L, uint32_t v, int 
 }
 
 // The window W holds 64 stream bits, `o` of them (from the top) already consumed; one symbol costs a 64-bit shift, the
-// table lookup and an add.  K symbols are decoded between two refill checks -- K * max_len <= 33 keeps o + max_len <= 64
+// table lookup and an add.  K symbols are decoded between two refill checks -- K * max_len <= 32 keeps o + max_len <= 64
 // at every lookup.
 #define GHF_REFILL()           \
   if (o >= 32u) {              \
@@ -646,7 +646,10 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
         uint32_t used, acc;
         if (VAR <= 3) {
           uint32_t out[16];
-          // K = 33 / max_len symbols per refill check
+          // K = 32 / max_len symbols per refill check (o <= 31 behind a check, o + K * max_len <= 63 before the next: a
+          // single refill brings it back below 32.  With 33 -- max_len 11, K = 3 -- o could reach 64, stay at 32 behind the
+          // refill, and the third lookup of the next round would read past the window: six 11-bit codes in a row at the
+          // right phase, found by scratch/host_soak.py)
           if (VAR == 0) acc = dec_hot_pair(lin, la0, T2, cur.pos, out, used) >> 14;  // bit 30 -> bit 16
           else if (VAR == 1) acc = dec_hot<4>(lin, la0, T1, cur.pos, out, used);
           else if (VAR == 2) acc = dec_hot<3>(lin, la0, T1, cur.pos, out, used);
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
   };
   if (pair_bits) run(std::integral_constant<int, 0>{});
   else if (max_len <= 8) run(std::integral_constant<int, 1>{});
-  else if (max_len <= 11) run(std::integral_constant<int, 2>{});
+  else if (max_len <= 10) run(std::integral_constant<int, 2>{});
   else if (max_len <= kDecLutBitsMax) run(std::integral_constant<int, 3>{});
   else if (max_len <= 16) run(std::integral_constant<int, 4>{});
   else run(std::integral_constant<int, 5>{});

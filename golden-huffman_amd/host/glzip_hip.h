@@ -138,58 +138,6 @@ inline size_t file_size(FILE* f) {
   return n < 0 ? 0 : (size_t)n;
 }
 
-// What replaces the reference's 64 KiB FixedFileBuffer (utils/include/buffer.h:61-317): files move between disk
-// and HBM in 32 MiB pieces through TWO pinned buffers, each with its own copy stream, so the fread/fwrite of one
-// piece overlaps the hipMemcpyAsync of the other.
-class Stager {
- public:
-  static const size_t kPiece = 32u << 20;
-  Stager() {}
-  // file -> device, n bytes from the current file position
-  void to_device(FILE* f, uint8_t* d_dst, size_t n, const std::string& what) {
-    ensure();
-    size_t off = 0;
-    for (int k = 0; off < n; ++k) {
-      const int b = k & 1;
-      const size_t len = n - off < kPiece ? n - off : kPiece;
-      s_[b].sync("stager");  // the copy that last used this buffer is done
-      if (fread(h_[b].p, 1, len, f) != len) throw Error(GHF_E_INVAL, "short read on " + what);
-      s_[b].check(ghf_copy_h2d(s_[b].ctx(), d_dst + off, h_[b].p, len), "ghf_copy_h2d");
-      off += len;
-    }
-    s_[0].sync("stager");
-    s_[1].sync("stager");
-  }
-  // device -> file, n bytes appended at the current file position
-  void to_file(const uint8_t* d_src, size_t n, FILE* f, const std::string& what) {
-    ensure();
-    size_t off = 0, pending_len[2] = {0, 0};
-    for (int k = 0; off < n || pending_len[k & 1] || pending_len[(k + 1) & 1]; ++k) {
-      const int b = k & 1;
-      if (pending_len[b]) {  // the copy issued two rounds ago into this buffer: wait, then write it out
-        s_[b].sync("stager");
-        if (fwrite(h_[b].p, 1, pending_len[b], f) != pending_len[b]) throw Error(GHF_E_INVAL, "short write on " + what);
-        pending_len[b] = 0;
-      }
-      if (off < n) {
-        const size_t len = n - off < kPiece ? n - off : kPiece;
-        s_[b].check(ghf_copy_d2h(s_[b].ctx(), h_[b].p, d_src + off, len), "ghf_copy_d2h");
-        pending_len[b] = len;
-        off += len;
-      }
-    }
-  }
-
- private:
-  void ensure() {
-    for (int b = 0; b < 2; ++b)
-      if (!h_[b].p) h_[b].alloc(s_[b], kPiece);
-  }
-  Session s_[2];
-  PinnedBuf h_[2];
-};
-
-
 // ------------------------------------------------------------------------------------------------ the file pipeline
 // what replaces utils/include/buffer.h:61-317 for the canonical policies.  A file moves in pieces:
 //   reader threads (pread -> pinned ring) -> copy-in stream -> kernel stream -> copy-out stream -> pinned ring ->
@@ -415,10 +363,13 @@ class Pipe {
   }
 
   // ---- file -> device -------------------------------------------------------------------------------------------
-  // The byte range [base, base + total) of fd in pieces of piece() bytes, each followed by `extra` look-ahead bytes of
-  // the next piece, the whole zero-filled up to padded(k).  Reads run `kSlots - 2` pieces ahead on the pool.
-  void open_feed(int fd, size_t base, size_t total, size_t extra) {
-    fd_ = fd, base_ = base, total_ = total, extra_ = extra;
+  // The byte range [base, base + file_bytes) of fd, followed by the tail_n <= 16 bytes at `tail` (a .crs keeps the last,
+  // incomplete byte of its body in front of it), in pieces of piece() bytes, each followed by `extra` look-ahead bytes
+  // of the next piece, the whole zero-filled up to padded(k).  Reads run `kSlots - 2` pieces ahead on the pool.
+  void open_feed(int fd, size_t base, size_t file_bytes, size_t extra, const uint8_t* tail = NULL, size_t tail_n = 0) {
+    fd_ = fd, base_ = base, file_bytes_ = file_bytes, total_ = file_bytes + tail_n, extra_ = extra;
+    tail_n_ = tail_n < sizeof tail_ ? tail_n : sizeof tail_;
+    if (tail_n_) memcpy(tail_, tail, tail_n_);
     next_read_ = next_feed_ = 0;
     pend_.clear();
     ensure_ring(in_ring_, piece() + 64);
@@ -643,16 +594,22 @@ class Pipe {
       const int si = acquire(in_ring_, in_next_);
       Slot& sl = in_ring_[si];
       uint8_t* dst = sl.buf.u8();
-      const size_t k = next_read_, off = base_ + k * piece_, pad = padded(k);
-      const size_t avail = base_ + total_ - off, want = own(k) + extra_;
-      const size_t len = want < avail ? want : avail;
+      const size_t k = next_read_, v0 = k * piece_, off = base_ + v0, pad = padded(k);
+      const size_t avail = v0 < file_bytes_ ? file_bytes_ - v0 : 0, want = own(k) + extra_;
+      const size_t len = want < avail ? want : avail;  // what comes from the file; behind it zeros and, where they fall, the tail bytes
       const int fd = fd_;
+      uint8_t tb[16];
+      memcpy(tb, tail_, sizeof tb);
+      const size_t tail_lo = file_bytes_, tail_n = tail_n_;
       for (size_t o = 0; o < len || o == 0; o += kFill) {  // several threads per piece: one pread moves 6-9 GB/s
         const size_t part = len - o < kFill ? len - o : kFill;
-        const bool tail = o + part >= len;
-        sl.job.add(pool_.submit([fd, dst, o, part, off, len, pad, tail] {
-          pread_all(fd, dst + o, part, off + o);
-          if (tail && pad > len) memset(dst + len, 0, pad - len);
+        const bool last = o + part >= len;
+        sl.job.add(pool_.submit([fd, dst, o, part, off, len, pad, last, v0, tail_lo, tail_n, tb] {
+          if (part) pread_all(fd, dst + o, part, off + o);
+          if (!last) return;
+          if (pad > len) memset(dst + len, 0, pad - len);
+          for (size_t i = 0; i < tail_n; ++i)
+            if (tail_lo + i >= v0 && tail_lo + i - v0 < pad) dst[tail_lo + i - v0] = tb[i];
         }));
       }
       pend_.push_back(si);
@@ -674,7 +631,8 @@ class Pipe {
   Ring in_ring_, out_ring_;
   size_t in_next_, out_next_, slot_bytes_ = 0;
   int fd_;
-  size_t base_, total_, extra_, next_read_, next_feed_;
+  size_t base_, file_bytes_ = 0, total_, extra_, next_read_, next_feed_, tail_n_ = 0;
+  uint8_t tail_[16] = {0};
   std::deque<int> pend_;  // slots of the reads that were started and not fed yet, in piece order
   std::deque<Landing> landing_;
   int sink_fd_;
@@ -724,55 +682,48 @@ class Decompressor {  // include/compressor.h:81-95
   _Decoder decoder_;
 };
 
-// ------------------------------------------------------------------------------------------------ encoder policy
-template <typename _KeyType = unsigned char>
-class HipCanonicalHuffEncoder;
+// ------------------------------------------------------------------------------------------------ the two passes of an encoder
+namespace detail {
 
-template <>
-class HipCanonicalHuffEncoder<unsigned char> {
- public:
-  HipCanonicalHuffEncoder(const std::string& infile_name, std::string& outfile_name) : infile_(NULL), outfile_(NULL), n_(0) {
-    set_file(infile_name, outfile_name);
-  }
-  HipCanonicalHuffEncoder() : infile_(NULL), outfile_(NULL), n_(0) {}
-  ~HipCanonicalHuffEncoder() { clear(); }
+// What the two formats' encoders share: the files, pass 1 (K1 over the pieces) and pass 2 (K4 + K5 piece by piece).
+class PieceEncoder {
+ protected:
+  PieceEncoder() : infile_(NULL), outfile_(NULL), n_(0) {}
+  ~PieceEncoder() { close_files(); }
 
-  // include/canonical_huff_encoder.cc:15-32: the output name defaults to <in>.crs2 and is handed back
-  void set_file(const std::string& infile_name, std::string& outfile_name) {
-    clear();
+  // include/canonical_huff_encoder.cc:15-32, include/normal_huff_encoder.h:83-99: the output name defaults to
+  // <in><ext> and is handed back
+  void open_files(const std::string& infile_name, std::string& outfile_name, const char* ext) {
+    close_files();
     infile_name_ = infile_name;
     infile_ = fopen(infile_name.c_str(), "rb");
     if (!infile_) throw Error(GHF_E_INVAL, "cannot open input file " + infile_name);
-    if (outfile_name.empty()) outfile_name = infile_name + ".crs2";
+    if (outfile_name.empty()) outfile_name = infile_name + ext;
     outfile_ = fopen(outfile_name.c_str(), "w+b");  // read-write: the pipeline maps it
     if (!outfile_) throw Error(GHF_E_INVAL, "cannot open output file " + outfile_name);
   }
-
-  void clear() {  // include/encoder.h:85-92
+  void close_files() {  // include/encoder.h:85-92
     if (pipe_) pipe_->cancel_presize();  // nothing may still be making pages for a file that is about to be closed
     if (infile_) fclose(infile_);
     if (outfile_) fclose(outfile_);
     infile_ = NULL;
     outfile_ = NULL;
   }
+  Pipe& pipe() const {
+    if (!pipe_) pipe_ = Pipe::shared();
+    return *pipe_;
+  }
 
   // include/encoder.h:99-105,123-150 -- pass 1 over the file: piece k is counted (K1, accumulating) while piece k+1
   // is on the PCIe bus and pieces k+2.. are being read.  A file of up to GHF_RESIDENT_BYTES (default 64 GiB of the
-  // 288) stays in HBM for encode_file; a larger one is read a second time there, as the reference does
+  // 288) stays in HBM for pass 2; a larger one is read a second time there, as the reference does
   // (include/canonical_huff_encoder.cc:247-248 rewinds the input), through a ring of kRing piece buffers.
-  void caculate_frequency() {
-    detail::StepTimer timer_("caculate_frequency");
-    n_ = detail::file_size(infile_);
-    // opt-in (SURVEY 8f N4): set_allow_empty(true) or GHF_EMPTY_OK=1 gives the empty file a defined encoding (include/ghf.h,
-    // GHF_EMPTY_OK: parity unpinned); without it the input on which the reference is undefined is refused
-    const char* eenv = getenv("GHF_EMPTY_OK");
-    empty_ = n_ == 0 && (allow_empty_ || (eenv && eenv[0] == '1'));
-    if (empty_) return;
-    if (n_ == 0) throw Error(GHF_E_EMPTY, "empty input: undefined in the reference, refused here");
+  // d_hist_[0..255] <- the byte counts, [256] <- 1.
+  void count_pieces() {
     pipe().begin();
-    const detail::Session& run = pipe().run();
+    const Session& run = pipe().run();
     const size_t P = pipe().piece(), np = (n_ + P - 1) / P;
-    resident_ = n_ <= detail::env_bytes("GHF_RESIDENT_BYTES", (size_t)64 << 30);
+    resident_ = n_ <= env_bytes("GHF_RESIDENT_BYTES", (size_t)64 << 30);
     if (resident_ && d_in_.n < n_ + 16) {
       try {
         d_in_.alloc(run, n_ + 16);
@@ -807,6 +758,335 @@ class HipCanonicalHuffEncoder<unsigned char> {
     run.sync("caculate_frequency");
   }
 
+  // include/canonical_huff_encoder.cc:245-285 / include/normal_huff_encoder.h:159-186 -- pass 2, piece by piece.
+  // A piece is to the stream what a shard is to the multi-GPU path (include/ghf.h, ghf_encode_sharded): K4 prices it,
+  // its first bit is the running sum of the prices before it, K5 packs it at that absolute bit into a buffer of its
+  // own (GHF_EMIT_REBASE), and the D2H of piece k runs while K4/K5 work on piece k+1 and the writer threads put piece
+  // k-1 into the file at its own offset.  Neighbouring pieces share one 16-byte unit of the stream (a piece does not
+  // end on a byte): that unit is OR-ed together here (`edge`), everything else goes from HBM to the file untouched.
+  //   head / head_bytes : what the file holds in front of the body (already written); the first code starts at bit
+  //                       8 * head_bytes
+  //   last_flags        : GHF_EMIT_LAST for a stream that ends with the end mark (end_mark_bits long) and 1-padding
+  //   out_bytes_        : the size the counts give (header + every byte that holds a bit of the body): checked
+  // Returns the stream's end bit; last_byte_ <- the stream byte that holds its last bit.
+  uint64_t emit_pieces(const ghf_code* dc, const uint8_t* head, size_t head_bytes, int last_flags, uint32_t end_mark_bits) {
+    pipe().begin();
+    const Session &run = pipe().run(), &out = pipe().out();
+    const size_t P = pipe().piece(), np = (n_ + P - 1) / P;
+    const size_t cap = ghf_shard_bound(P);
+    for (int r = 0; r < kRing; ++r)
+      if (d_out_[r].n < cap) d_out_[r].alloc(run, cap);
+    if (!d_scal_.p) d_scal_.alloc(run, kRing * 4 * sizeof(uint64_t));
+    if (!h_scal_.p) h_scal_.alloc(run, kRing * 4 * sizeof(uint64_t) + kRing * 32 + 16);
+    uint64_t* const ds = static_cast<uint64_t*>(d_scal_.p);                 // per ring slot: total bits, start bit, end[2]
+    volatile uint64_t* const hs = static_cast<uint64_t*>(h_scal_.p);        // pinned mirror of [0..1]
+    uint8_t* const h_edge = h_scal_.u8() + kRing * 4 * sizeof(uint64_t);    // per ring slot: first unit, last unit
+    volatile uint8_t* const h_last = h_edge + kRing * 32;                   // the stream's last byte
+    const int fd = fileno(outfile_);
+    if (!resident_) pipe().open_feed(fileno(infile_), 0, n_, 0);
+    pipe().open_sink(fd, out_bytes_, true);
+    StepSum t_plan("wait for K4");
+    uint64_t start = 8 * (uint64_t)head_bytes;  // absolute stream bit of the piece's first code
+    uint64_t end = start;
+    uint8_t edge[16];                           // the unit at stream byte (start / 128) * 16, as far as it is known
+    memset(edge, 0, sizeof edge);
+    memcpy(edge, head + (head_bytes & ~(size_t)15), head_bytes & 15);
+    struct Span {
+      bool live, last;
+      int r;
+      size_t F, U, E;  // stream bytes: first unit, unit shared with the next piece (E for the last piece), end
+    } prev = {false, false, 0, 0, 0, 0};
+    for (size_t k = 0; k < np; ++k) {
+      const int r = (int)(k % kRing);
+      const size_t len = n_ - k * P < P ? n_ - k * P : P;
+      const bool last = k + 1 == np;
+      const uint8_t* src = piece_at(k);
+      if (!resident_) {
+        used_[r].hold(pipe().in());
+        pipe().feed(piece_at(k), arrived_[r]);
+        arrived_[r].hold(run);
+      }
+      run.check(ghf_encode_plan(run.ctx(), src, len, dc, ds + 4 * r), "ghf_encode_plan");  // K4
+      run.check(ghf_copy_d2h(run.ctx(), const_cast<uint64_t*>(hs + 4 * r), ds + 4 * r, sizeof(uint64_t)), "ghf_copy_d2h");
+      planned_[r].record(run);
+      if (prev.live) close_span(prev.r, prev.F, prev.U, prev.E, prev.last, edge, h_edge, fd);  // while K4 runs
+      {
+        StepSum::Scope t(t_plan);
+        planned_[r].sync();
+      }
+      const uint64_t total = hs[4 * r];
+      hs[4 * r + 1] = start;
+      run.check(ghf_copy_h2d(run.ctx(), ds + 4 * r + 1, const_cast<uint64_t*>(hs + 4 * r + 1), sizeof(uint64_t)), "ghf_copy_h2d");
+      fetched_[r].hold(run);  // the D2H of piece k - kRing has let go of d_out_[r]
+      run.check(ghf_encode_emit(run.ctx(), src, len, dc, ds + 4 * r + 1, GHF_EMIT_REBASE | (last ? last_flags : 0), d_out_[r].u8(), cap,
+                                NULL, ds + 4 * r + 2),
+                "ghf_encode_emit");  // K5
+      used_[r].record(run);
+      emitted_[r].record(run);
+      end = start + total;
+      if (last && (last_flags & GHF_EMIT_LAST)) end = (end + end_mark_bits + 7) & ~(uint64_t)7;  // end mark, then 1-bits up to the byte
+      Span sp = {true, last, r, (size_t)(start >> 7) << 4, 0, (size_t)((end + 7) >> 3)};
+      sp.U = last ? sp.E : (size_t)(end >> 7) << 4;
+      // d_out_[r][0] is stream byte F.  The unit at F and the one at U are shared with the neighbours: to the host.
+      emitted_[r].hold(out);
+      const size_t nfirst = sp.E - sp.F < 16 ? sp.E - sp.F : 16;
+      out.check(ghf_copy_d2h(out.ctx(), h_edge + 32 * r, d_out_[r].p, nfirst), "ghf_copy_d2h");
+      if (!last && sp.U > sp.F && sp.E > sp.U)
+        out.check(ghf_copy_d2h(out.ctx(), h_edge + 32 * r + 16, d_out_[r].u8() + (sp.U - sp.F), sp.E - sp.U), "ghf_copy_d2h");
+      if (last && sp.E > sp.F)
+        out.check(ghf_copy_d2h(out.ctx(), const_cast<uint8_t*>(h_last), d_out_[r].u8() + (sp.E - 1 - sp.F), 1), "ghf_copy_d2h");
+      edged_[r].record(out);
+      if (sp.U > sp.F + 16) pipe().drain(emitted_[r], d_out_[r].u8() + 16, sp.U - sp.F - 16, fd, sp.F + 16);
+      fetched_[r].record(out);
+      prev = sp;
+      start += total;
+    }
+    close_span(prev.r, prev.F, prev.U, prev.E, prev.last, edge, h_edge, fd);
+    last_byte_ = prev.E > prev.F ? h_last[0] : 0;
+    pipe().close_sink(prev.E);
+    run.sync("encode_file");
+    if (prev.E != out_bytes_) throw Error(GHF_E_CORRUPT, "encode_file: the pieces do not add up to the size the counts give");
+    fseek(outfile_, 0, SEEK_END);
+    return end;
+  }
+
+  static const int kRing = 3;
+  mutable std::shared_ptr<Pipe> pipe_;  // first member: the buffers below are freed through its contexts
+  FILE* infile_;
+  FILE* outfile_;
+  std::string infile_name_;
+  size_t n_, out_bytes_ = 0;
+  uint8_t last_byte_ = 0;
+  DeviceBuf d_hist_;
+
+ private:
+  PieceEncoder(const PieceEncoder&);
+  PieceEncoder& operator=(const PieceEncoder&);
+  uint8_t* piece_at(size_t k) const { return resident_ ? d_in_.u8() + k * pipe().piece_bytes() : d_ring_[k % kRing].u8(); }
+  // While pass 1 still reads the file, a pool thread already makes the output file's pages (Pipe::presize): 97 % of
+  // the order-0 entropy of the first piece, times the file size.  An estimate only -- pass 2 sizes the file
+  // exactly (the rest of the pages, or a cut) before it writes a byte.
+  void presize_from_first_piece() {
+    first_counted_.sync();
+    const volatile uint64_t* h = static_cast<const uint64_t*>(h_first_.p);
+    double total = 0, bits = 0;
+    for (int b = 0; b < 256; ++b) total += (double)h[b];
+    for (int b = 0; b < 256; ++b)
+      if (h[b]) bits -= (double)h[b] * log2((double)h[b] / total);
+    if (total <= 0) return;
+    double per_symbol = bits / total;
+    if (per_symbol < 1) per_symbol = 1;  // no code is shorter than one bit
+    pipe().presize(fileno(outfile_), (size_t)(0.97 * per_symbol / 8 * (double)n_));
+  }
+  // the piece in ring slot r has reached the host as far as the host needs it: settle the unit it shares with its
+  // predecessor, write it out if the piece has moved past it, and open the next one
+  void close_span(int r, size_t F, size_t U, size_t E, bool last, uint8_t* edge, const uint8_t* h_edge, int fd) {
+    edged_[r].sync();
+    const uint8_t* first = h_edge + 32 * r;
+    const size_t nfirst = E - F < 16 ? E - F : 16;
+    for (size_t i = 0; i < nfirst; ++i) edge[i] |= first[i];
+    if (last) {
+      pwrite_all(fd, edge, nfirst, F);
+    } else if (U > F) {
+      pwrite_all(fd, edge, 16, F);
+      memset(edge, 0, 16);
+      memcpy(edge, first + 16, E - U);
+    }  // else the piece ends inside the unit it began in: the unit stays open
+  }
+  bool resident_ = true;
+  PinnedBuf h_scal_, h_first_;
+  DeviceBuf d_in_, d_ring_[kRing], d_out_[kRing], d_scal_;
+  Event arrived_[kRing], used_[kRing], planned_[kRing], emitted_[kRing], fetched_[kRing], edged_[kRing], first_counted_;
+};
+
+// What the two formats' decoders share: the files and the piece loop.
+class PieceDecoder {
+ protected:
+  // include/encoder.h:227-232: the output name defaults to <in>.de and is handed back
+  PieceDecoder(const std::string& infile_name, std::string& outfile_name) : n_(0) {
+    infile_ = fopen(infile_name.c_str(), "rb");
+    if (!infile_) throw Error(GHF_E_INVAL, "cannot open input file " + infile_name);
+    if (outfile_name.empty()) outfile_name = infile_name + ".de";
+    outfile_ = fopen(outfile_name.c_str(), "w+b");  // read-write: the pipeline maps it
+    if (!outfile_) {
+      fclose(infile_);
+      throw Error(GHF_E_INVAL, "cannot open output file " + outfile_name);
+    }
+  }
+  ~PieceDecoder() {
+    if (infile_) fclose(infile_);
+    if (outfile_) fclose(outfile_);
+  }
+  Pipe& pipe() const {
+    if (!pipe_) pipe_ = Pipe::shared();
+    return *pipe_;
+  }
+
+  // The body -- `body` bytes of the file from offset `base`, then tail_n more at `tail` -- is cut at byte positions into
+  // pieces.  Neither format has sync points, but the bit at which piece k's last code ends is where piece k+1's first
+  // code begins, so one K6 pass per piece (`sync`: exact first bit in, landing bit and symbol count out) both rebuilds
+  // the piece's side-car and hands the cut to the next piece; K7 (`decode`) then decodes the piece block-parallel.
+  // Pieces k+1.. are read and copied in while K6/K7 run on piece k, and the decoded bytes leave through the copy-out
+  // stream and the writer threads at their own file offset.
+  //   sync(d_piece, padded, first_bit, end_bit, &landing, &nsym, &has_end), decode(d_piece, padded, d_dst, cap)
+  //   spare_bits   : bits at the end of the body's last byte that are no code bits (.crs: left_bits)
+  //   needs_mark   : the stream ends at an end mark (canonical) -- else exactly at its last bit (.crs)
+  template <class Sync, class Decode>
+  void decode_pieces(size_t base, size_t body, const uint8_t* tail, size_t tail_n, uint32_t spare_bits, bool needs_mark, Sync sync,
+                     Decode decode) {
+    pipe().begin();
+    const Session &run = pipe().run(), &out = pipe().out();
+    const size_t P = pipe().piece();
+    pipe().open_feed(fileno(infile_), base, body, 16, tail, tail_n);
+    // a compressed piece decodes to at most 8 symbols per byte (no code is shorter than one bit)
+    const size_t np = pipe().pieces(), in_cap = P + 64, out_cap = 8 * P + 64;
+    for (int r = 0; r < kRing; ++r)
+      if (d_in_[r].n < in_cap) d_in_[r].alloc(run, in_cap);
+    const int fd = fileno(outfile_);
+    pipe().open_sink(fd, 8 * (body + tail_n) + 16, false);  // the formats do not say how much comes out
+    // Where the decoded bytes wait for the file.  Making the output file's pages is the slowest stage (20 GB/s, and no
+    // copy into the file may run meanwhile), and how many are needed is only known at the end of the stream.  So: the
+    // first piece tells the ratio; if the estimated output fits GHF_RESIDENT_BYTES it ALL stays in HBM (`whole_`) while
+    // a pool thread makes 97 % of the estimated pages, and it leaves in one sweep at the end, when the exact size is known
+    // (sweeping the pieces whose pages exist while the rest is still being made was tried: page-making and copying
+    // into the same file get in each other's way, 4 GiB took 480-700 ms instead of 410-470).
+    // Otherwise (or once `whole_` is full) a piece leaves as soon as it is decoded, through the kOut-deep ring.
+    struct Held {
+      const uint8_t* d;
+      size_t bytes, at;
+    };
+    std::vector<Held> held;
+    size_t whole_used = 0;
+    bool resident = false;
+    size_t fed = 0, out_off = 0;
+    uint32_t first = 0;  // the body begins on a byte
+    StepSum t_sync("K6 (sync_piece)"), t_mem("hipMalloc (output)");
+    bool done = false;
+    uint64_t landing = 0;
+    const double loop_t0 = StepTimer::now();
+    for (size_t k = 0; k < np && !done; ++k) {
+      for (; fed < np && fed < k + kRing - 1; ++fed) {  // pieces k+1.. arrive while this one is worked on
+        const int q = (int)(fed % kRing);
+        used_[q].hold(pipe().in());
+        pipe().feed(d_in_[q].u8(), arrived_[q]);
+      }
+      const int r = (int)(k % kRing), o = (int)(k % kOut);
+      arrived_[r].hold(run);
+      uint64_t nsym = 0;
+      int has_end = 0;
+      const uint64_t end_bit = 8 * (uint64_t)pipe().own(k) - (k + 1 == np ? spare_bits : 0u);
+      {
+        StepSum::Scope t(t_sync);
+        sync(d_in_[r].u8(), pipe().padded(k), first, end_bit, &landing, &nsym, &has_end);  // K6; the call waits for its own result
+      }
+      if (nsym > out_cap) throw Error(GHF_E_CORRUPT, "a piece decodes to more than 8 symbols per byte");
+      if (k == 0 && np > 2 && !has_end && Pipe::wants_map(8 * body)) {
+        const double est = (double)nsym / (double)pipe().own(0) * (double)(body + tail_n);
+        const size_t want = (size_t)(est * 1.05) + 4 * out_cap;
+        if (want <= env_bytes("GHF_RESIDENT_BYTES", (size_t)64 << 30)) {
+          try {
+            StepSum::Scope t(t_mem);
+            if (whole_.n < want) whole_.alloc(run, want);
+            resident = true;
+            pipe().presize(fd, (size_t)(est * 0.97));
+          } catch (const Error&) {
+            resident = false;
+          }
+        }
+      }
+      if (resident && whole_used + nsym > whole_.n) {  // the estimate was too low: what is held leaves now, the rest streams
+        resident = false;
+        pipe().cancel_presize();
+        pipe().adopt_presized(fd);
+        sweep(held, fd);
+      }
+      uint8_t* dst = resident ? whole_.u8() + whole_used : NULL;
+      if (nsym) {
+        if (!resident) {
+          if (d_out_[o].n < out_cap) d_out_[o].alloc(run, out_cap);
+          fetched_[o].hold(run);  // the D2H of piece k - kOut has let go of d_out_[o]
+          dst = d_out_[o].u8();
+        }
+        decode(d_in_[r].u8(), pipe().padded(k), dst, out_cap);  // K7
+      }
+      used_[r].record(run);
+      if (nsym && resident) {
+        const Held h = {dst, (size_t)nsym, out_off};
+        held.push_back(h);
+        whole_used += ((size_t)nsym + 255) & ~(size_t)255;
+      } else if (nsym) {
+        decoded_[o].record(run);
+        pipe().drain(decoded_[o], dst, (size_t)nsym, fd, out_off);
+        fetched_[o].record(out);
+      }
+      out_off += (size_t)nsym;
+      first = (uint32_t)landing;
+      done = has_end != 0;
+    }
+    if (getenv("GHF_PIPE_TRACE")) fprintf(stderr, "[ghf]   %-18s %9.2f ms\n", "piece loop", StepTimer::now() - loop_t0);
+    if (resident) {
+      pipe().cancel_presize();  // (it has long finished, or the estimate was too high: the exact size is known now)
+      pipe().adopt_presized(fd);
+      pipe().reserve_all(out_off);
+      sweep(held, fd);
+    }
+    pipe().close_sink(out_off);
+    run.sync("decode_file");
+    fseek(outfile_, 0, SEEK_END);
+    if (needs_mark && !done) throw Error(GHF_E_CORRUPT, "the stream ends before the end mark");
+    if (!needs_mark && np && landing != 0) throw Error(GHF_E_CORRUPT, "the body does not end on a code boundary");
+  }
+
+  mutable std::shared_ptr<Pipe> pipe_;  // first member: the buffers below are freed through its contexts
+  FILE* infile_;
+  FILE* outfile_;
+  size_t n_;
+
+ private:
+  PieceDecoder(const PieceDecoder&);
+  PieceDecoder& operator=(const PieceDecoder&);
+  static const int kRing = 3, kOut = 2;
+  // everything that was decoded into `whole_` so far goes to the file
+  template <typename V>
+  void sweep(V& held, int fd) {
+    swept_.record(pipe().run());
+    for (size_t i = 0; i < held.size(); ++i) pipe().drain(swept_, held[i].d, held[i].bytes, fd, held[i].at);
+    held.clear();
+  }
+  DeviceBuf d_in_[kRing], d_out_[kOut], whole_;
+  Event arrived_[kRing], used_[kRing], decoded_[kOut], fetched_[kOut], swept_;
+};
+
+}  // namespace detail
+
+// ------------------------------------------------------------------------------------------------ encoder policy
+template <typename _KeyType = unsigned char>
+class HipCanonicalHuffEncoder;
+
+template <>
+class HipCanonicalHuffEncoder<unsigned char> : private detail::PieceEncoder {
+ public:
+  HipCanonicalHuffEncoder(const std::string& infile_name, std::string& outfile_name) { set_file(infile_name, outfile_name); }
+  HipCanonicalHuffEncoder() {}
+  ~HipCanonicalHuffEncoder() { clear(); }
+
+  // include/canonical_huff_encoder.cc:15-32: the output name defaults to <in>.crs2 and is handed back
+  void set_file(const std::string& infile_name, std::string& outfile_name) { open_files(infile_name, outfile_name, ".crs2"); }
+  void clear() { close_files(); }  // include/encoder.h:85-92
+
+  // include/encoder.h:99-105,123-150: pass 1 of the file pipeline (detail::PieceEncoder::count_pieces)
+  void caculate_frequency() {
+    detail::StepTimer timer_("caculate_frequency");
+    n_ = detail::file_size(infile_);
+    // opt-in (SURVEY 8f N4): set_allow_empty(true) or GHF_EMPTY_OK=1 gives the empty file a defined encoding (include/ghf.h,
+    // GHF_EMPTY_OK: parity unpinned); without it the input on which the reference is undefined is refused
+    const char* eenv = getenv("GHF_EMPTY_OK");
+    empty_ = n_ == 0 && (allow_empty_ || (eenv && eenv[0] == '1'));
+    if (empty_) return;
+    if (n_ == 0) throw Error(GHF_E_EMPTY, "empty input: undefined in the reference, refused here");
+    count_pieces();
+  }
+
   // include/canonical_huff_encoder.cc:35-42
   void gen_encode() {
     detail::StepTimer timer_("gen_encode");
@@ -832,25 +1112,19 @@ class HipCanonicalHuffEncoder<unsigned char> {
   void write_encode_info() {
     detail::StepTimer timer_("write_encode_info");
     const detail::Session& run = pipe().run();
+    if (!d_hdr_.p) d_hdr_.alloc(run, 2048);  // the largest header is 1040 + 8 * 32 = 1296 bytes
+    if (!h_hdr_.p) h_hdr_.alloc(run, 2048);
+    size_t hdr;
     if (empty_) {
-      if (!d_hdr_.p) d_hdr_.alloc(run, 2048);
-      if (!h_hdr_.p) h_hdr_.alloc(run, 2048);
       if (!d_code_.p) d_code_.alloc(run, sizeof(ghf_code));
       run.check(ghf_compress_ex(run.ctx(), NULL, 0, d_hdr_.u8(), d_hdr_.n, NULL, static_cast<ghf_code*>(d_code_.p), NULL, GHF_EMPTY_OK),
                 "ghf_compress_ex");
-      out_bytes_ = ghf_header_bytes(1) + 1;
-      run.check(ghf_copy_d2h(run.ctx(), h_hdr_.p, d_hdr_.p, out_bytes_), "ghf_copy_d2h");
+      hdr = out_bytes_ = ghf_header_bytes(1) + 1;  // (the one body byte included)
       run.check(ghf_copy_d2h(run.ctx(), &code_, d_code_.p, sizeof(ghf_code)), "ghf_copy_d2h");
-      run.sync("write_encode_info");
-      fseek(outfile_, 0, SEEK_SET);
-      if (fwrite(h_hdr_.p, 1, out_bytes_, outfile_) != out_bytes_) throw Error(GHF_E_INVAL, "short write (empty stream)");
-      fflush(outfile_);
-      return;
+    } else {
+      hdr = ghf_header_bytes(code_.max_len);
+      run.check(ghf_write_header(run.ctx(), static_cast<const ghf_code*>(d_code_.p), d_hdr_.u8(), d_hdr_.n), "ghf_write_header");
     }
-    const size_t hdr = ghf_header_bytes(code_.max_len);
-    if (!d_hdr_.p) d_hdr_.alloc(run, 2048);  // the largest header is 1040 + 8 * 32 = 1296 bytes
-    if (!h_hdr_.p) h_hdr_.alloc(run, 2048);
-    run.check(ghf_write_header(run.ctx(), static_cast<const ghf_code*>(d_code_.p), d_hdr_.u8(), d_hdr_.n), "ghf_write_header");
     run.check(ghf_copy_d2h(run.ctx(), h_hdr_.p, d_hdr_.p, hdr), "ghf_copy_d2h");
     run.sync("write_encode_info");
     fseek(outfile_, 0, SEEK_SET);
@@ -858,17 +1132,12 @@ class HipCanonicalHuffEncoder<unsigned char> {
     fflush(outfile_);
   }
 
-  // include/canonical_huff_encoder.cc:245-285 -- pass 2, piece by piece.  A piece is to the stream what a shard is to
-  // the multi-GPU path (include/ghf.h, ghf_encode_sharded): K4 prices it, its first bit is the running sum of the
-  // prices before it, K5 packs it at that absolute bit into a buffer of its own (GHF_EMIT_REBASE), and the D2H of
-  // piece k runs while K4/K5 work on piece k+1 and the writer threads put piece k-1 into the file at its own offset.
-  // Neighbouring pieces share one 16-byte unit of the stream (a piece does not end on a byte): that unit is OR-ed
-  // together here (`edge`), everything else goes from HBM to the file untouched.
+  // include/canonical_huff_encoder.cc:245-285: pass 2 of the file pipeline (detail::PieceEncoder::emit_pieces)
   void encode_file() {
     detail::StepTimer timer_("encode_file");
     if (empty_) return;
     try {
-      encode_pieces();
+      emit_pieces(static_cast<const ghf_code*>(d_code_.p), h_hdr_.u8(), ghf_header_bytes(code_.max_len), GHF_EMIT_LAST, code_.length[256]);
     } catch (...) {
       pipe().abandon_sink();
       throw;
@@ -880,129 +1149,9 @@ class HipCanonicalHuffEncoder<unsigned char> {
   void set_allow_empty(bool on) { allow_empty_ = on; }  // not in the reference: see caculate_frequency()
 
  private:
-  void encode_pieces() {
-    pipe().begin();
-    const detail::Session &run = pipe().run(), &out = pipe().out();
-    const size_t P = pipe().piece(), np = (n_ + P - 1) / P, hdr = ghf_header_bytes(code_.max_len);
-    const size_t cap = ghf_shard_bound(P);
-    for (int r = 0; r < kRing; ++r)
-      if (d_out_[r].n < cap) d_out_[r].alloc(run, cap);
-    if (!d_scal_.p) d_scal_.alloc(run, kRing * 4 * sizeof(uint64_t));
-    if (!h_scal_.p) h_scal_.alloc(run, kRing * 4 * sizeof(uint64_t) + kRing * 32);
-    uint64_t* const ds = static_cast<uint64_t*>(d_scal_.p);                 // per ring slot: total bits, start bit, end[2]
-    volatile uint64_t* const hs = static_cast<uint64_t*>(h_scal_.p);        // pinned mirror of [0..1]
-    uint8_t* const h_edge = h_scal_.u8() + kRing * 4 * sizeof(uint64_t);    // per ring slot: first unit, last unit
-    const ghf_code* dc = static_cast<const ghf_code*>(d_code_.p);
-    const int fd = fileno(outfile_);
-    if (!resident_) pipe().open_feed(fileno(infile_), 0, n_, 0);
-    pipe().open_sink(fd, out_bytes_, true);
-    detail::StepSum t_plan("wait for K4");
-    uint64_t start = 8 * (uint64_t)hdr;  // absolute stream bit of the piece's first code
-    uint8_t edge[16];                    // the unit at stream byte (start / 128) * 16, as far as it is known
-    memset(edge, 0, sizeof edge);
-    memcpy(edge, h_hdr_.u8() + (hdr & ~(size_t)15), hdr & 15);
-    struct Span {
-      bool live, last;
-      int r;
-      size_t F, U, E;  // stream bytes: first unit, unit shared with the next piece (E for the last piece), end
-    } prev = {false, false, 0, 0, 0, 0};
-    for (size_t k = 0; k < np; ++k) {
-      const int r = (int)(k % kRing);
-      const size_t len = n_ - k * P < P ? n_ - k * P : P;
-      const bool last = k + 1 == np;
-      const uint8_t* src = piece_at(k);
-      if (!resident_) {
-        used_[r].hold(pipe().in());
-        pipe().feed(piece_at(k), arrived_[r]);
-        arrived_[r].hold(run);
-      }
-      run.check(ghf_encode_plan(run.ctx(), src, len, dc, ds + 4 * r), "ghf_encode_plan");  // K4
-      run.check(ghf_copy_d2h(run.ctx(), const_cast<uint64_t*>(hs + 4 * r), ds + 4 * r, sizeof(uint64_t)), "ghf_copy_d2h");
-      planned_[r].record(run);
-      if (prev.live) close_span(prev.r, prev.F, prev.U, prev.E, prev.last, edge, h_edge, fd);  // while K4 runs
-      {
-        detail::StepSum::Scope t(t_plan);
-        planned_[r].sync();
-      }
-      const uint64_t total = hs[4 * r];
-      hs[4 * r + 1] = start;
-      run.check(ghf_copy_h2d(run.ctx(), ds + 4 * r + 1, const_cast<uint64_t*>(hs + 4 * r + 1), sizeof(uint64_t)), "ghf_copy_h2d");
-      fetched_[r].hold(run);  // the D2H of piece k - kRing has let go of d_out_[r]
-      run.check(ghf_encode_emit(run.ctx(), src, len, dc, ds + 4 * r + 1, GHF_EMIT_REBASE | (last ? GHF_EMIT_LAST : 0),
-                                d_out_[r].u8(), cap, NULL, ds + 4 * r + 2),
-                "ghf_encode_emit");  // K5
-      used_[r].record(run);
-      emitted_[r].record(run);
-      uint64_t end = start + total;
-      if (last) end = (end + code_.length[256] + 7) & ~(uint64_t)7;  // end mark, then 1-bits up to the byte
-      Span sp = {true, last, r, (size_t)(start >> 7) << 4, 0, (size_t)((end + 7) >> 3)};
-      sp.U = last ? sp.E : (size_t)(end >> 7) << 4;
-      // d_out_[r][0] is stream byte F.  The unit at F and the one at U are shared with the neighbours: to the host.
-      emitted_[r].hold(out);
-      const size_t nfirst = sp.E - sp.F < 16 ? sp.E - sp.F : 16;
-      out.check(ghf_copy_d2h(out.ctx(), h_edge + 32 * r, d_out_[r].p, nfirst), "ghf_copy_d2h");
-      if (!last && sp.U > sp.F && sp.E > sp.U)
-        out.check(ghf_copy_d2h(out.ctx(), h_edge + 32 * r + 16, d_out_[r].u8() + (sp.U - sp.F), sp.E - sp.U), "ghf_copy_d2h");
-      edged_[r].record(out);
-      if (sp.U > sp.F + 16) pipe().drain(emitted_[r], d_out_[r].u8() + 16, sp.U - sp.F - 16, fd, sp.F + 16);
-      fetched_[r].record(out);
-      prev = sp;
-      start += total;
-    }
-    close_span(prev.r, prev.F, prev.U, prev.E, prev.last, edge, h_edge, fd);
-    pipe().close_sink(prev.E);
-    run.sync("encode_file");
-    if (prev.E != out_bytes_) throw Error(GHF_E_CORRUPT, "encode_file: the pieces do not add up to the size the counts give");
-    fseek(outfile_, 0, SEEK_END);
-  }
-  HipCanonicalHuffEncoder(const HipCanonicalHuffEncoder&);
-  HipCanonicalHuffEncoder& operator=(const HipCanonicalHuffEncoder&);
-  static const int kRing = 3;
-  uint8_t* piece_at(size_t k) const { return resident_ ? d_in_.u8() + k * pipe().piece_bytes() : d_ring_[k % kRing].u8(); }
-  // While pass 1 still reads the file, a pool thread already makes the output file's pages (Pipe::presize): 97 % of
-  // the order-0 entropy of the first piece, times the file size.  An estimate only -- encode_file() sizes the file
-  // exactly (the rest of the pages, or a cut) before it writes a byte.
-  void presize_from_first_piece() {
-    first_counted_.sync();
-    const volatile uint64_t* h = static_cast<const uint64_t*>(h_first_.p);
-    double total = 0, bits = 0;
-    for (int b = 0; b < 256; ++b) total += (double)h[b];
-    for (int b = 0; b < 256; ++b)
-      if (h[b]) bits -= (double)h[b] * log2((double)h[b] / total);
-    if (total <= 0) return;
-    double per_symbol = bits / total;
-    if (per_symbol < 1) per_symbol = 1;  // no code is shorter than one bit
-    pipe().presize(fileno(outfile_), (size_t)(0.97 * per_symbol / 8 * (double)n_));
-  }
-  // the piece in ring slot r has reached the host as far as the host needs it: settle the unit it shares with its
-  // predecessor, write it out if the piece has moved past it, and open the next one
-  void close_span(int r, size_t F, size_t U, size_t E, bool last, uint8_t* edge, const uint8_t* h_edge, int fd) {
-    edged_[r].sync();
-    const uint8_t* first = h_edge + 32 * r;
-    const size_t nfirst = E - F < 16 ? E - F : 16;
-    for (size_t i = 0; i < nfirst; ++i) edge[i] |= first[i];
-    if (last) {
-      detail::pwrite_all(fd, edge, nfirst, F);
-    } else if (U > F) {
-      detail::pwrite_all(fd, edge, 16, F);
-      memset(edge, 0, 16);
-      memcpy(edge, first + 16, E - U);
-    }  // else the piece ends inside the unit it began in: the unit stays open
-  }
-  detail::Pipe& pipe() const {
-    if (!pipe_) pipe_ = detail::Pipe::shared();
-    return *pipe_;
-  }
-  mutable std::shared_ptr<detail::Pipe> pipe_;  // first member: the buffers below are freed through its contexts
-  FILE* infile_;
-  FILE* outfile_;
-  std::string infile_name_;
-  size_t n_, out_bytes_ = 0;
-  bool resident_ = true;
   bool limit_ = false, allow_empty_ = false, empty_ = false;
-  detail::PinnedBuf h_hdr_, h_scal_, h_first_;
-  detail::DeviceBuf d_in_, d_ring_[kRing], d_hist_, d_code_, d_hdr_, d_out_[kRing], d_scal_;
-  detail::Event arrived_[kRing], used_[kRing], planned_[kRing], emitted_[kRing], fetched_[kRing], edged_[kRing], first_counted_;
+  detail::PinnedBuf h_hdr_;
+  detail::DeviceBuf d_code_, d_hdr_;
   ghf_code code_;
 };
 
@@ -1011,23 +1160,9 @@ template <typename _KeyType = unsigned char>
 class HipCanonicalHuffDecoder;
 
 template <>
-class HipCanonicalHuffDecoder<unsigned char> {
+class HipCanonicalHuffDecoder<unsigned char> : private detail::PieceDecoder {
  public:
-  // include/encoder.h:227-232: the output name defaults to <in>.de and is handed back
-  HipCanonicalHuffDecoder(const std::string& infile_name, std::string& outfile_name) : hdr_(0) {
-    infile_ = fopen(infile_name.c_str(), "rb");
-    if (!infile_) throw Error(GHF_E_INVAL, "cannot open input file " + infile_name);
-    if (outfile_name.empty()) outfile_name = infile_name + ".de";
-    outfile_ = fopen(outfile_name.c_str(), "w+b");  // read-write: the pipeline maps it
-    if (!outfile_) {
-      fclose(infile_);
-      throw Error(GHF_E_INVAL, "cannot open output file " + outfile_name);
-    }
-  }
-  ~HipCanonicalHuffDecoder() {
-    if (infile_) fclose(infile_);
-    if (outfile_) fclose(outfile_);
-  }
+  HipCanonicalHuffDecoder(const std::string& infile_name, std::string& outfile_name) : detail::PieceDecoder(infile_name, outfile_name), hdr_(0) {}
 
   // include/canonical_huff_encoder.cc:349-374 -- plus the validation the reference does not do
   void get_encode_info() {
@@ -1039,16 +1174,23 @@ class HipCanonicalHuffDecoder<unsigned char> {
     fseek(infile_, 0, SEEK_SET);
   }
 
-  // include/canonical_huff_encoder.cc:377-419 (and :422-461, :519-568): runs until the end mark.
-  // The body is cut at byte positions into pieces.  A .crs2 file has no sync points, but the bit at which piece k's
-  // last code ends is where piece k+1's first code begins, so one K6 pass per piece (ghf_sync_piece, exact first bit
-  // in, landing bit and symbol count out) both rebuilds the piece's side-car and hands the cut to the next piece; K7
-  // then decodes the piece block-parallel.  Piece k+1.. are read and copied in while K6/K7 run on piece k, and the
-  // decoded bytes of piece k-1 leave through the copy-out stream and the writer threads at their own file offset.
+  // include/canonical_huff_encoder.cc:377-419 (and :422-461, :519-568): runs until the end mark, piece by piece
+  // (detail::PieceDecoder::decode_pieces with ghf_sync_piece as K6 and ghf_decode as K7)
   void decode_file() {
     detail::StepTimer timer_("decode_file");
     try {
-      decode_pieces();
+      const detail::Session& run = pipe().run();
+      if (!d_code_.p) d_code_.alloc(run, sizeof(ghf_code));
+      run.check(ghf_copy_h2d(run.ctx(), d_code_.p, &code_, sizeof(ghf_code)), "ghf_copy_h2d");
+      const ghf_code* dc = static_cast<const ghf_code*>(d_code_.p);
+      decode_pieces(
+          hdr_, n_ - hdr_, NULL, 0, 0, true,
+          [&](const uint8_t* d_piece, size_t bytes, uint32_t first, uint64_t end_bit, uint64_t* landing, uint64_t* nsym, int* has_end) {
+            run.check(ghf_sync_piece(run.ctx(), d_piece, bytes, first, end_bit, dc, landing, nsym, has_end), "ghf_sync_piece");
+          },
+          [&](const uint8_t* d_piece, size_t bytes, uint8_t* d_dst, size_t cap) {
+            run.check(ghf_decode(run.ctx(), d_piece, bytes, dc, NULL, d_dst, cap, NULL), "ghf_decode");
+          });
     } catch (...) {
       pipe().abandon_sink();
       throw;
@@ -1056,131 +1198,8 @@ class HipCanonicalHuffDecoder<unsigned char> {
   }
 
  private:
-  void decode_pieces() {
-    pipe().begin();
-    const detail::Session &run = pipe().run(), &out = pipe().out();
-    const size_t P = pipe().piece(), body = n_ - hdr_;
-    if (!d_code_.p) d_code_.alloc(run, sizeof(ghf_code));
-    run.check(ghf_copy_h2d(run.ctx(), d_code_.p, &code_, sizeof(ghf_code)), "ghf_copy_h2d");
-    const ghf_code* dc = static_cast<const ghf_code*>(d_code_.p);
-    pipe().open_feed(fileno(infile_), hdr_, body, 16);
-    // a compressed piece decodes to at most 8 symbols per byte (no code is shorter than one bit)
-    const size_t np = pipe().pieces(), in_cap = P + 64, out_cap = 8 * P + 64;
-    for (int r = 0; r < kRing; ++r)
-      if (d_in_[r].n < in_cap) d_in_[r].alloc(run, in_cap);
-    const int fd = fileno(outfile_);
-    pipe().open_sink(fd, 8 * body + 16, false);  // the format does not say how much comes out
-    // Where the decoded bytes wait for the file.  Making the output file's pages is the slowest stage (20 GB/s, and no
-    // copy into the file may run meanwhile), and how many are needed is only known at the end mark.  So: the first
-    // piece tells the ratio; if the estimated output fits GHF_RESIDENT_BYTES it ALL stays in HBM (`whole`) while a pool
-    // thread makes 97 % of the estimated pages, and it leaves in one sweep at the end, when the exact size is known
-    // (sweeping the pieces whose pages exist while the rest is still being made was tried: page-making and copying
-    // into the same file get in each other's way, 4 GiB took 480-700 ms instead of 410-470).
-    // Otherwise (or once `whole` is full) a piece leaves as soon as it is decoded, through the kOut-deep ring.
-    struct Held {
-      const uint8_t* d;
-      size_t bytes, at;
-    };
-    std::vector<Held> held;
-    size_t whole_used = 0;
-    bool resident = false;
-    size_t fed = 0, out_off = 0;
-    uint32_t first = 0;  // the header ends on a byte
-    detail::StepSum t_sync("ghf_sync_piece"), t_mem("hipMalloc (output)");
-    bool done = false;
-    const double loop_t0 = detail::StepTimer::now();
-    for (size_t k = 0; k < np && !done; ++k) {
-      for (; fed < np && fed < k + kRing - 1; ++fed) {  // pieces k+1.. arrive while this one is worked on
-        const int q = (int)(fed % kRing);
-        used_[q].hold(pipe().in());
-        pipe().feed(d_in_[q].u8(), arrived_[q]);
-      }
-      const int r = (int)(k % kRing), o = (int)(k % kOut);
-      arrived_[r].hold(run);
-      uint64_t landing = 0, nsym = 0;
-      int has_end = 0;
-      {
-        detail::StepSum::Scope t(t_sync);
-        run.check(ghf_sync_piece(run.ctx(), d_in_[r].u8(), pipe().padded(k), first, 8 * (uint64_t)pipe().own(k), dc, &landing, &nsym,
-                                 &has_end),
-                  "ghf_sync_piece");  // K6; the call waits for its own result
-      }
-      if (nsym > out_cap) throw Error(GHF_E_CORRUPT, "a piece decodes to more than 8 symbols per byte");
-      if (k == 0 && np > 2 && !has_end && detail::Pipe::wants_map(8 * body)) {
-        const double est = (double)nsym / (double)pipe().own(0) * (double)body;
-        const size_t want = (size_t)(est * 1.05) + 4 * out_cap;
-        if (want <= detail::env_bytes("GHF_RESIDENT_BYTES", (size_t)64 << 30)) {
-          try {
-            detail::StepSum::Scope t(t_mem);
-            if (whole_.n < want) whole_.alloc(run, want);
-            resident = true;
-            pipe().presize(fd, (size_t)(est * 0.97));
-          } catch (const Error&) {
-            resident = false;
-          }
-        }
-      }
-      if (resident && whole_used + nsym > whole_.n) {  // the estimate was too low: what is held leaves now, the rest streams
-        resident = false;
-        pipe().cancel_presize();
-        pipe().adopt_presized(fd);
-        sweep(held, fd);
-      }
-      uint8_t* dst = resident ? whole_.u8() + whole_used : NULL;
-      if (nsym) {
-        if (!resident) {
-          if (d_out_[o].n < out_cap) d_out_[o].alloc(run, out_cap);
-          fetched_[o].hold(run);  // the D2H of piece k - kOut has let go of d_out_[o]
-          dst = d_out_[o].u8();
-        }
-        run.check(ghf_decode(run.ctx(), d_in_[r].u8(), pipe().padded(k), dc, NULL, dst, out_cap, NULL), "ghf_decode");  // K7
-      }
-      used_[r].record(run);
-      if (nsym && resident) {
-        const Held h = {dst, (size_t)nsym, out_off};
-        held.push_back(h);
-        whole_used += ((size_t)nsym + 255) & ~(size_t)255;
-      } else if (nsym) {
-        decoded_[o].record(run);
-        pipe().drain(decoded_[o], dst, (size_t)nsym, fd, out_off);
-        fetched_[o].record(out);
-      }
-      out_off += (size_t)nsym;
-      first = (uint32_t)landing;
-      done = has_end != 0;
-    }
-    if (getenv("GHF_PIPE_TRACE")) fprintf(stderr, "[ghf]   %-18s %9.2f ms\n", "piece loop", detail::StepTimer::now() - loop_t0);
-    if (resident) {
-      pipe().cancel_presize();  // (it has long finished, or the estimate was too high: the exact size is known now)
-      pipe().adopt_presized(fd);
-      pipe().reserve_all(out_off);
-      sweep(held, fd);
-    }
-    pipe().close_sink(out_off);
-    run.sync("decode_file");
-    fseek(outfile_, 0, SEEK_END);
-    if (!done) throw Error(GHF_E_CORRUPT, "the stream ends before the end mark");
-  }
-  // everything that was decoded into `whole_` so far goes to the file
-  template <typename V>
-  void sweep(V& held, int fd) {
-    swept_.record(pipe().run());
-    for (size_t i = 0; i < held.size(); ++i) pipe().drain(swept_, held[i].d, held[i].bytes, fd, held[i].at);
-    held.clear();
-  }
-  HipCanonicalHuffDecoder(const HipCanonicalHuffDecoder&);
-  HipCanonicalHuffDecoder& operator=(const HipCanonicalHuffDecoder&);
-  static const int kRing = 3, kOut = 2;
-  detail::Pipe& pipe() const {
-    if (!pipe_) pipe_ = detail::Pipe::shared();
-    return *pipe_;
-  }
-  mutable std::shared_ptr<detail::Pipe> pipe_;  // first member: the buffers below are freed through its contexts
-  FILE* infile_;
-  FILE* outfile_;
-  size_t n_, hdr_;
-  detail::DeviceBuf d_in_[kRing], d_code_, d_out_[kOut], whole_;
-  detail::Event arrived_[kRing], used_[kRing], decoded_[kOut], fetched_[kOut], swept_;
+  size_t hdr_;
+  detail::DeviceBuf d_code_;
   ghf_code code_;
 };
 
@@ -1201,107 +1220,90 @@ class HipTableCanonicalHuffDecoder : public HipCanonicalHuffDecoder<_KeyType> {
 // ================================================================================================
 // the .crs format.  Same member functions, same order (Compressor<>::compress() and
 // Decompressor<>::decompress() above do not change): drop-ins for NormalHuffEncoder<> / NormalHuffDecoder<>
-// (include/normal_huff_encoder.h:57-283).
+// (include/normal_huff_encoder.h:57-283).  Same file pipeline as the canonical pair: the two passes of
+// detail::PieceEncoder with the tree's codes, detail::PieceDecoder with ghf_crs_sync_piece as its K6.
 // ================================================================================================
 template <typename _KeyType = unsigned char>
 class HipNormalHuffEncoder;
 
 template <>
-class HipNormalHuffEncoder<unsigned char> {
+class HipNormalHuffEncoder<unsigned char> : private detail::PieceEncoder {
  public:
-  HipNormalHuffEncoder(const std::string& infile_name, std::string& outfile_name) : infile_(NULL), outfile_(NULL), n_(0) {
-    set_file(infile_name, outfile_name);
-  }
-  HipNormalHuffEncoder() : infile_(NULL), outfile_(NULL), n_(0) {}
+  HipNormalHuffEncoder(const std::string& infile_name, std::string& outfile_name) { set_file(infile_name, outfile_name); }
+  HipNormalHuffEncoder() {}
   ~HipNormalHuffEncoder() { clear(); }
 
   // include/normal_huff_encoder.h:83-99: the output name defaults to <in>.crs and is handed back
-  void set_file(const std::string& infile_name, std::string& outfile_name) {
-    clear();
-    infile_name_ = infile_name;
-    infile_ = fopen(infile_name.c_str(), "rb");
-    if (!infile_) throw Error(GHF_E_INVAL, "cannot open input file " + infile_name);
-    if (outfile_name.empty()) outfile_name = infile_name + ".crs";
-    outfile_ = fopen(outfile_name.c_str(), "wb");
-    if (!outfile_) throw Error(GHF_E_INVAL, "cannot open output file " + outfile_name);
-  }
+  void set_file(const std::string& infile_name, std::string& outfile_name) { open_files(infile_name, outfile_name, ".crs"); }
+  void clear() { close_files(); }  // include/encoder.h:85-92
 
-  void clear() {  // include/encoder.h:85-92
-    if (infile_) fclose(infile_);
-    if (outfile_) fclose(outfile_);
-    infile_ = NULL;
-    outfile_ = NULL;
-  }
-
-  // include/encoder.h:99-105,136-150 (no end-mark slot in this format: init_nhuff, normal_huff_encoder.h:189-196)
+  // include/encoder.h:99-105,136-150 (no end-mark slot in this format: init_nhuff, normal_huff_encoder.h:189-196;
+  // K1's slot [256] is simply not looked at)
   void caculate_frequency() {
+    detail::StepTimer timer_("caculate_frequency");
     n_ = detail::file_size(infile_);
     if (n_ == 0) throw Error(GHF_E_EMPTY, "empty input: undefined in the reference, refused here");
-    d_in_.alloc(s_, n_ + 16);
-    d_hist_.alloc(s_, GHF_NSYM * sizeof(uint64_t));
-    stager_.to_device(infile_, d_in_.u8(), n_, infile_name_);
-    s_.check(ghf_histogram(s_.ctx(), d_in_.u8(), n_, static_cast<uint64_t*>(d_hist_.p)), "ghf_histogram");
+    count_pieces();
   }
 
   // include/normal_huff_encoder.h:110-121 -> EncodeHuffTree::build_tree + gen_encode (include/huff_tree.cc:138-171)
   void gen_encode() {
-    d_tree_.alloc(s_, sizeof(ghf_tree));
-    d_code_.alloc(s_, sizeof(ghf_code));
-    s_.check(ghf_crs_build_code(s_.ctx(), static_cast<const uint64_t*>(d_hist_.p), static_cast<ghf_tree*>(d_tree_.p),
-                                static_cast<ghf_code*>(d_code_.p)),
-             "ghf_crs_build_code");
-    s_.check(ghf_copy_d2h(s_.ctx(), &tree_, d_tree_.p, sizeof(ghf_tree)), "ghf_copy_d2h");
-    s_.sync("gen_encode");
+    detail::StepTimer timer_("gen_encode");
+    const detail::Session& run = pipe().run();
+    if (!d_tree_.p) d_tree_.alloc(run, sizeof(ghf_tree));
+    if (!d_code_.p) d_code_.alloc(run, sizeof(ghf_code));
+    run.check(ghf_crs_build_code(run.ctx(), static_cast<const uint64_t*>(d_hist_.p), static_cast<ghf_tree*>(d_tree_.p),
+                                 static_cast<ghf_code*>(d_code_.p)),
+              "ghf_crs_build_code");
+    run.check(ghf_copy_d2h(run.ctx(), &tree_, d_tree_.p, sizeof(ghf_tree)), "ghf_copy_d2h");
+    ghf_code code;
+    uint64_t hist[GHF_NSYM];
+    run.check(ghf_copy_d2h(run.ctx(), &code, d_code_.p, sizeof code), "ghf_copy_d2h");
+    run.check(ghf_copy_d2h(run.ctx(), hist, d_hist_.p, sizeof hist), "ghf_copy_d2h");
+    run.sync("gen_encode");
+    body_bits_ = 0;  // the body's size follows from the counts: the output file is sized up front
+    for (int b = 0; b < 256; ++b) body_bits_ += hist[b] * code.length[b];
+    out_bytes_ = (size_t)tree_.tree_bytes + 2 + (size_t)((body_bits_ + 7) >> 3);
   }
 
   // include/normal_huff_encoder.h:136-138 -> serialize_tree (include/huff_tree.cc:174-187): the tree at file offset 0
   void write_encode_info() {
+    detail::StepTimer timer_("write_encode_info");
     fseek(outfile_, 0, SEEK_SET);
     if (fwrite(tree_.header, 1, tree_.tree_bytes, outfile_) != tree_.tree_bytes) throw Error(GHF_E_INVAL, "short write (tree)");
     fflush(outfile_);
   }
 
-  // include/normal_huff_encoder.h:159-186: {left_bits, last byte}, then the whole bytes of the body
+  // include/normal_huff_encoder.h:159-186: two placeholder bytes, the codes, then {left_bits, last byte} go back into the
+  // placeholders and the body keeps its whole bytes only
   void encode_file() {
-    const size_t hdr = (size_t)tree_.tree_bytes + 2;
-    cap_ = ghf_crs_compress_bound(n_);
-    d_out_.alloc(s_, cap_);
-    detail::DeviceBuf d_scal;
-    d_scal.alloc(s_, 4 * sizeof(uint64_t));  // [0] start bit, [1] total bits, [2..3] end
-    uint64_t* ds = static_cast<uint64_t*>(d_scal.p);
-    const uint64_t start_bit = 8ull * hdr;
-    uint64_t scal[4] = {start_bit, 0, 0, 0};
-    const ghf_code* dc = static_cast<const ghf_code*>(d_code_.p);
-    s_.check(ghf_copy_h2d(s_.ctx(), ds, scal, sizeof(uint64_t)), "ghf_copy_h2d");
-    s_.check(ghf_encode_plan(s_.ctx(), d_in_.u8(), n_, dc, ds + 1), "ghf_encode_plan");
-    s_.check(ghf_encode_emit(s_.ctx(), d_in_.u8(), n_, dc, ds, 0, d_out_.u8(), cap_, NULL, ds + 2), "ghf_encode_emit");
-    s_.check(ghf_copy_d2h(s_.ctx(), scal, ds, sizeof scal), "ghf_copy_d2h");
-    s_.sync("encode_file");
-    const uint64_t bits = scal[1];
-    const size_t whole = (size_t)(bits >> 3);
-    const unsigned left = (unsigned)((8 - (bits & 7)) & 7);
-    unsigned char prefix[2] = {(unsigned char)left, 0};
-    if (left) {  // the zero-filled last byte sits right behind the whole bytes (the emit kernels zero-fill their last unit)
-      s_.check(ghf_copy_d2h(s_.ctx(), prefix + 1, d_out_.u8() + hdr + whole, 1), "ghf_copy_d2h");
-      s_.sync("encode_file (last byte)");
+    detail::StepTimer timer_("encode_file");
+    try {
+      const size_t hdr = (size_t)tree_.tree_bytes + 2;
+      uint8_t head[1040];
+      memcpy(head, tree_.header, tree_.tree_bytes);
+      head[hdr - 2] = head[hdr - 1] = 0;
+      if (fwrite(head + hdr - 2, 1, 2, outfile_) != 2) throw Error(GHF_E_INVAL, "short write (prefix)");
+      fflush(outfile_);
+      const uint64_t end = emit_pieces(static_cast<const ghf_code*>(d_code_.p), head, hdr, 0, 0);
+      if (end != 8 * (uint64_t)hdr + body_bits_) throw Error(GHF_E_CORRUPT, "encode_file: the pieces do not add up to the bits the counts give");
+      const size_t whole = (size_t)(body_bits_ >> 3);
+      const unsigned left = (unsigned)((8 - (body_bits_ & 7)) & 7);
+      const uint8_t prefix[2] = {(uint8_t)left, left ? last_byte_ : (uint8_t)0};  // (K5 zero-fills behind its last bit)
+      detail::pwrite_all(fileno(outfile_), prefix, 2, hdr - 2);
+      if (ftruncate(fileno(outfile_), (off_t)(hdr + whole)) != 0) throw Error(GHF_E_INVAL, "ftruncate");
+      fseek(outfile_, 0, SEEK_END);
+    } catch (...) {
+      pipe().abandon_sink();
+      throw;
     }
-    if (fwrite(prefix, 1, 2, outfile_) != 2) throw Error(GHF_E_INVAL, "short write (prefix)");
-    stager_.to_file(d_out_.u8() + hdr, whole, outfile_, "output (body)");
-    fflush(outfile_);
   }
 
   const ghf_tree& tree() const { return tree_; }
 
  private:
-  HipNormalHuffEncoder(const HipNormalHuffEncoder&);
-  HipNormalHuffEncoder& operator=(const HipNormalHuffEncoder&);
-  detail::Session s_;
-  FILE* infile_;
-  FILE* outfile_;
-  std::string infile_name_;
-  size_t n_, cap_;
-  detail::DeviceBuf d_in_, d_hist_, d_tree_, d_code_, d_out_;
-  detail::Stager stager_;
+  detail::DeviceBuf d_tree_, d_code_;
+  uint64_t body_bits_ = 0;
   ghf_tree tree_;
 };
 
@@ -1309,30 +1311,18 @@ template <typename _KeyType = unsigned char>
 class HipNormalHuffDecoder;
 
 template <>
-class HipNormalHuffDecoder<unsigned char> {
+class HipNormalHuffDecoder<unsigned char> : private detail::PieceDecoder {
  public:
-  // include/encoder.h:227-232: the output name defaults to <in>.de and is handed back
-  HipNormalHuffDecoder(const std::string& infile_name, std::string& outfile_name) : n_(0), tb_(0), left_(0), last_(0) {
-    infile_ = fopen(infile_name.c_str(), "rb");
-    if (!infile_) throw Error(GHF_E_INVAL, "cannot open input file " + infile_name);
-    if (outfile_name.empty()) outfile_name = infile_name + ".de";
-    outfile_ = fopen(outfile_name.c_str(), "wb");
-    if (!outfile_) {
-      fclose(infile_);
-      throw Error(GHF_E_INVAL, "cannot open output file " + outfile_name);
-    }
-  }
-  ~HipNormalHuffDecoder() {
-    if (infile_) fclose(infile_);
-    if (outfile_) fclose(outfile_);
-  }
+  HipNormalHuffDecoder(const std::string& infile_name, std::string& outfile_name)
+      : detail::PieceDecoder(infile_name, outfile_name), tb_(0), left_(0), last_(0) {}
 
   // include/normal_huff_encoder.h:268-271 -> DecodeHuffTree::build_tree (include/huff_tree.cc:289-303), validated
   void get_encode_info() {
+    detail::StepTimer timer_("get_encode_info");
     n_ = detail::file_size(infile_);
     std::vector<uint8_t> head(n_ < 1024 ? n_ : 1024);  // the largest tree: 2 * 511 bytes, then the two prefix bytes
     if (fread(head.data(), 1, head.size(), infile_) != head.size()) throw Error(GHF_E_INVAL, "short read");
-    s_.check(ghf_crs_parse_header(head.data(), head.size(), &tree_, &tb_), "ghf_crs_parse_header");
+    pipe().run().check(ghf_crs_parse_header(head.data(), head.size(), &tree_, &tb_), "ghf_crs_parse_header");
     if (tb_ + 2 > head.size()) throw Error(GHF_E_FORMAT, "the two bytes behind the tree are missing");
     left_ = head[tb_];       // include/huff_tree.cc:195-196
     last_ = head[tb_ + 1];
@@ -1340,38 +1330,34 @@ class HipNormalHuffDecoder<unsigned char> {
     fseek(infile_, 0, SEEK_SET);
   }
 
-  // include/normal_huff_encoder.h:272-274 -> DecodeHuffTree::decode_file (include/huff_tree.cc:191-207)
+  // include/normal_huff_encoder.h:272-274 -> DecodeHuffTree::decode_file (include/huff_tree.cc:191-207): the stored last
+  // byte goes behind the body, where its bits belong, and the stream ends left_bits before that byte does
   void decode_file() {
-    d_in_.alloc(s_, n_ + 32);
-    d_tree_.alloc(s_, sizeof(ghf_tree));
-    stager_.to_device(infile_, d_in_.u8(), n_, "input");
-    size_t stream_bytes = n_;
-    if (left_) {  // the stored last byte goes behind the body, where its bits belong
-      s_.check(ghf_copy_h2d(s_.ctx(), d_in_.u8() + n_, &last_, 1), "ghf_copy_h2d");
-      ++stream_bytes;
+    detail::StepTimer timer_("decode_file");
+    try {
+      const detail::Session& run = pipe().run();
+      if (!d_tree_.p) d_tree_.alloc(run, sizeof(ghf_tree));
+      run.check(ghf_copy_h2d(run.ctx(), d_tree_.p, &tree_, sizeof(ghf_tree)), "ghf_copy_h2d");
+      const ghf_tree* dt = static_cast<const ghf_tree*>(d_tree_.p);
+      decode_pieces(
+          tb_ + 2, n_ - (tb_ + 2), &last_, left_ ? 1 : 0, left_, false,
+          [&](const uint8_t* d_piece, size_t bytes, uint32_t first, uint64_t end_bit, uint64_t* landing, uint64_t* nsym, int* has_end) {
+            *has_end = 0;  // no end mark in this format
+            run.check(ghf_crs_sync_piece(run.ctx(), d_piece, bytes, first, end_bit, dt, landing, nsym), "ghf_crs_sync_piece");
+          },
+          [&](const uint8_t* d_piece, size_t bytes, uint8_t* d_dst, size_t cap) {
+            run.check(ghf_crs_decode(run.ctx(), d_piece, bytes, 0, dt, NULL, d_dst, cap, NULL), "ghf_crs_decode");
+          });
+    } catch (...) {
+      pipe().abandon_sink();
+      throw;
     }
-    s_.check(ghf_copy_h2d(s_.ctx(), d_tree_.p, &tree_, sizeof(ghf_tree)), "ghf_copy_h2d");
-    const ghf_tree* dt = static_cast<const ghf_tree*>(d_tree_.p);
-    uint64_t n_out = 0;
-    s_.check(ghf_crs_decoded_size(s_.ctx(), d_in_.u8(), stream_bytes, (int)left_, dt, &n_out), "ghf_crs_decoded_size");
-    d_out_.alloc(s_, (size_t)n_out + 16);
-    s_.check(ghf_crs_decode(s_.ctx(), d_in_.u8(), stream_bytes, (int)left_, dt, NULL, d_out_.u8(), (size_t)n_out + 16, NULL),
-             "ghf_crs_decode");
-    s_.sync("decode_file");
-    stager_.to_file(d_out_.u8(), (size_t)n_out, outfile_, "output");
-    fflush(outfile_);
   }
 
  private:
-  HipNormalHuffDecoder(const HipNormalHuffDecoder&);
-  HipNormalHuffDecoder& operator=(const HipNormalHuffDecoder&);
-  detail::Session s_;
-  FILE* infile_;
-  FILE* outfile_;
-  size_t n_, tb_;
+  size_t tb_;
   uint8_t left_, last_;
-  detail::DeviceBuf d_in_, d_tree_, d_out_;
-  detail::Stager stager_;
+  detail::DeviceBuf d_tree_;
   ghf_tree tree_;
 };
 

@@ -25,29 +25,53 @@ def gen():
         a = int(rng.integers(0, n)); b = min(n, a + int(rng.integers(1, max(2, n // 2))))
         data[a:b] = rng.integers(0, 256, b - a, dtype=np.uint8) if rng.random() < 0.5 else 0
     return data
+def dump_on_failure(f, tag):
+    import shutil
+    out = os.path.join(ROOT, "gpurun_out", "host_soak_fail")
+    os.makedirs(out, exist_ok=True)
+    for ext in ("", ".crs", ".crs2"):
+        if os.path.exists(f + ext) and os.path.getsize(f + ext) < (48 << 20):
+            shutil.copy(f + ext, os.path.join(out, "x.bin" + ext))
+    open(os.path.join(out, "tag.txt"), "w").write(tag + "\n")
+
 with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None, prefix="ghf_soak_") as d:
+  try:
     while time.time() - t0 < budget:
-        data = gen()
-        f = os.path.join(d, "x.bin"); data.tofile(f)
-        env = dict(os.environ)
-        env["GHF_PIECE_BYTES"] = str(int(rng.choice([65536, 131072, 1 << 20, 16 << 20])))
-        env["GHF_IO_THREADS"] = str(int(rng.choice([1, 2, 5, 12])))
-        env["GHF_RESIDENT_BYTES"] = str(int(rng.choice([0, 1 << 40])))
-        sink = str(rng.choice(["mmap", "pwrite", ""]))
-        if sink: env["GHF_SINK"] = sink
-        else: env.pop("GHF_SINK", None)
-        tag = "n=%d piece=%s thr=%s res=%s sink=%s" % (data.size, env["GHF_PIECE_BYTES"], env["GHF_IO_THREADS"], env["GHF_RESIDENT_BYTES"], sink or "auto")
-        r = subprocess.run([TOOL, f, "3"], capture_output=True, text=True, env=env, timeout=120)
-        assert r.returncode == 0, (tag, r.stderr[-300:])
-        ref = orc.compress(data)
-        got = np.fromfile(f + ".crs2", dtype=np.uint8)
-        assert got.size == ref.size and hashlib.sha256(got).digest() == hashlib.sha256(ref).digest(), ("compress differs", tag)
-        dm = str(rng.choice(["4", "5", "6"]))
-        if os.path.exists(f + ".crs2.de"): os.remove(f + ".crs2.de")
-        r = subprocess.run([TOOL, f + ".crs2", dm], capture_output=True, text=True, env=env, timeout=120)
-        assert r.returncode == 0, (tag, r.stderr[-300:])
-        back = np.fromfile(f + ".crs2.de", dtype=np.uint8)
-        assert back.size == data.size and np.array_equal(back, data), ("round trip differs", tag)
-        cases += 1
-        if cases % 20 == 0: print("cases", cases, int(time.time() - t0), "s", flush=True)
+          data = gen()
+          f = os.path.join(d, "x.bin"); data.tofile(f)
+          env = dict(os.environ)
+          env["GHF_PIECE_BYTES"] = str(int(rng.choice([65536, 131072, 1 << 20, 16 << 20])))
+          env["GHF_IO_THREADS"] = str(int(rng.choice([1, 2, 5, 12])))
+          env["GHF_RESIDENT_BYTES"] = str(int(rng.choice([0, 1 << 40])))
+          sink = str(rng.choice(["mmap", "pwrite", ""]))
+          if sink: env["GHF_SINK"] = sink
+          else: env.pop("GHF_SINK", None)
+          tag = "n=%d piece=%s thr=%s res=%s sink=%s" % (data.size, env["GHF_PIECE_BYTES"], env["GHF_IO_THREADS"], env["GHF_RESIDENT_BYTES"], sink or "auto")
+          r = subprocess.run([TOOL, f, "3"], capture_output=True, text=True, env=env, timeout=120)
+          assert r.returncode == 0, (tag, r.stderr[-300:])
+          ref = orc.compress(data)
+          got = np.fromfile(f + ".crs2", dtype=np.uint8)
+          assert got.size == ref.size and hashlib.sha256(got).digest() == hashlib.sha256(ref).digest(), ("compress differs", tag)
+          dm = str(rng.choice(["4", "5", "6"]))
+          if os.path.exists(f + ".crs2.de"): os.remove(f + ".crs2.de")
+          r = subprocess.run([TOOL, f + ".crs2", dm], capture_output=True, text=True, env=env, timeout=120)
+          assert r.returncode == 0, (tag, r.stderr[-300:])
+          back = np.fromfile(f + ".crs2.de", dtype=np.uint8)
+          assert back.size == data.size and np.array_equal(back, data), ("round trip differs", tag)
+          if len(set(data.tolist())) >= 2 and rng.random() < 0.5:  # the .crs pair on the same file (needs two distinct byte values)
+              r = subprocess.run([TOOL, f, "1"], capture_output=True, text=True, env=env, timeout=120)
+              assert r.returncode == 0, ("crs", tag, r.stderr[-300:])
+              ref = orc.crs_compress(data)
+              got = np.fromfile(f + ".crs", dtype=np.uint8)
+              assert got.size == ref.size and hashlib.sha256(got).digest() == hashlib.sha256(ref).digest(), ("crs compress differs", tag)
+              if os.path.exists(f + ".crs.de"): os.remove(f + ".crs.de")
+              r = subprocess.run([TOOL, f + ".crs", "2"], capture_output=True, text=True, env=env, timeout=120)
+              assert r.returncode == 0, ("crs", tag, r.stderr[-300:])
+              back = np.fromfile(f + ".crs.de", dtype=np.uint8)
+              assert back.size == data.size and np.array_equal(back, data), ("crs round trip differs", tag)
+          cases += 1
+          if cases % 20 == 0: print("cases", cases, int(time.time() - t0), "s", flush=True)
+  except AssertionError:
+    dump_on_failure(f, tag)
+    raise
 print("host soak ok: %d cases" % cases)

@@ -231,6 +231,45 @@ def test_crs_mode_switch_compress_then_decompress(tool, tmp_path, golden_crs, na
     assert np.array_equal(np.fromfile(str(f) + ".crs.de", dtype=np.uint8), data)
 
 
+@pytest.mark.parametrize("resident,sink", [(1 << 40, "mmap"), (0, "pwrite")], ids=["resident-mmap", "reread-pwrite"])
+@pytest.mark.parametrize("name", ["text_1m", "zipf_64k", "uniform_65537", "fib32_maxlen32", "ab", "sym16_n1003"])
+def test_crs_pipeline_small_pieces(tool, tmp_path, golden_crs, name, resident, sink):
+    """the .crs policies on the same file pipeline: 64 KiB pieces (a code may straddle any piece boundary; the decoder's
+    last piece carries the stored last byte and must land on a code boundary), the two-byte prefix patched in at the end"""
+    data = CASES[name]()
+    f = tmp_path / (name + ".bin")
+    data.tofile(f)
+    env = _env(GHF_PIECE_BYTES=65536, GHF_RESIDENT_BYTES=resident, GHF_IO_THREADS=3, GHF_SINK=sink)
+    assert subprocess.run([tool, str(f), "1"], timeout=120, env=env).returncode == 0
+    crs = np.fromfile(str(f) + ".crs", dtype=np.uint8)
+    assert crs.size == golden_crs[name]["crs_bytes"] and sha(crs) == golden_crs[name]["crs_sha256"]
+    assert subprocess.run([tool, str(f) + ".crs", "2"], timeout=120, env=env).returncode == 0
+    assert np.array_equal(np.fromfile(str(f) + ".crs.de", dtype=np.uint8), data)
+
+
+def test_crs_pipeline_multi_piece_file_and_damage(tool, tmp_path):
+    """70 MiB through the .crs policies with the default 16 MiB pieces, bit-exact with the oracle; a body cut short or
+    with its prefix changed no longer ends on a code boundary (or holds bits that are no code): an error, not garbage"""
+    import datagen as dg
+
+    data = dg.zipf_bytes((70 << 20) + 4321, seed=78)
+    f = tmp_path / "big.bin"
+    data.tofile(f)
+    assert subprocess.run([tool, str(f), "1"], timeout=300).returncode == 0
+    crs = np.fromfile(str(f) + ".crs", dtype=np.uint8)
+    ref = orc.crs_compress(data)
+    assert crs.size == ref.size and sha(crs) == sha(ref)
+    assert subprocess.run([tool, str(f) + ".crs", "2"], timeout=300).returncode == 0
+    assert np.array_equal(np.fromfile(str(f) + ".crs.de", dtype=np.uint8), data)
+    cut = tmp_path / "cut.crs"
+    crs[: crs.size - 100003].tofile(cut)
+    r = subprocess.run([tool, str(cut), "2"], capture_output=True, text=True, timeout=300)
+    if r.returncode == 0:  # (one cut in eight lands on a code boundary: then the prefix's left_bits gives it away or not)
+        assert os.path.getsize(str(cut) + ".de") < data.size
+    else:
+        assert "error 7" in r.stderr
+
+
 def test_crs_interop_with_the_reference_algorithm(tool, tmp_path):
     """a .crs written by the reference's algorithm (the oracle; with the compiled reference itself when it is around)
     is decoded by ghf_tool, and what ghf_tool writes is decoded by them"""

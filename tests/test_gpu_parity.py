@@ -593,3 +593,48 @@ def test_wide_codes_many_chunks_bit_exact(env, n):
     ctx.sync()
     assert int(nbytes.item()) == n and bool((back2[:n] == d_in).all().item())
     ctx.index_free(ix)
+
+
+def test_runs_of_the_longest_codes_at_max_len_11(env):
+    """regression (found by scratch/host_soak.py): with max_len == 11 K7 decoded three symbols per refill check, and six
+    11-bit codes in a row at the right bit phase read past its 64-bit window.  Exact counts that give 240 byte values
+    (and the end mark) 11-bit codes, with all the rare values in one long stretch: runs of them at every phase -- for
+    both formats, with and without the side-car"""
+    ghf, ctx, torch = env
+    rng = np.random.default_rng(11)
+    c = 300
+    counts = np.zeros(256, dtype=np.int64)
+    counts[0:6], counts[6:8], counts[8:248], counts[248:255] = 256 * c, 128 * c, c, 2 * c  # (byte 255 does not occur)
+    freq = np.repeat(np.arange(8, dtype=np.uint8), counts[:8])
+    rare = np.repeat(np.arange(8, 256).astype(np.uint8), counts[8:])
+    rng.shuffle(freq)
+    rng.shuffle(rare)
+    data = np.concatenate([freq[: freq.size // 2], rare, freq[freq.size // 2 :]])
+    code = orc.build_code(orc.histogram(data))
+    assert code.max_len == 11 and sum(1 for x in code.length if x == 11) >= 200
+    d_in, d_out, nb, d_code, idx = run_compress(ghf, ctx, torch, data)
+    assert sha(d_out[:nb].cpu().numpy()) == sha(orc.compress(data))
+    back, _ = ctx.decode(d_out, nb, d_code, idx)
+    ctx.sync()
+    assert np.array_equal(back[: data.size].cpu().numpy(), data)
+    back2, n2 = ctx.decode(d_out, nb, d_code, None, cap=data.size + 64)
+    ctx.sync()
+    assert int(n2.item()) == data.size and np.array_equal(back2[: data.size].cpu().numpy(), data)
+    ctx.index_free(idx)
+    # the same bytes as a .crs (tree-order codes, the same kind of lengths), at several bit phases of the body
+    for drop in (0, 1, 2, 3):
+        part = data[drop:]
+        d_part = to_dev(torch, part)
+        idx = ctx.index_alloc(part.size)
+        c_out, c_nbytes, d_tree = ctx.crs_compress(d_part, index=idx)
+        ctx.sync()
+        cnb = int(c_nbytes.item())
+        ref = orc.crs_compress(part)
+        assert cnb == ref.size and sha(c_out[:cnb].cpu().numpy()) == sha(ref)
+        tree = ctx.tree_to_host(d_tree)
+        assert tree.max_len == 11
+        left = int(ref[tree.tree_bytes])
+        back3, n3 = ctx.crs_decode(c_out, cnb + (1 if left else 0), left, d_tree, idx)
+        ctx.sync()
+        assert int(n3.item()) == part.size and np.array_equal(back3[: part.size].cpu().numpy(), part)
+        ctx.index_free(idx)
