@@ -32,6 +32,10 @@ def gen():
     if rng.random() < 0.3 and n > 4096:  # nonstationary: a run of one symbol
         a = int(rng.integers(0, n - 1)); b = min(n, a + int(rng.integers(1, 100000)))
         data[a:b] = syms[0]
+    if rng.random() < 0.3 and n > 4096:  # ... or a stretch of the rare symbols only (runs of the longest codes, spans beyond K7's tile)
+        a = int(rng.integers(0, n - 1)); b = min(n, a + int(rng.integers(1, 300000)))
+        rare = syms[np.argsort(w)[: max(1, k // 2)]]
+        data[a:b] = rare[rng.integers(0, rare.size, b - a)]
     return data
 while time.time() - t0 < budget:
     data = gen(); n = data.size; cases += 1
