@@ -221,7 +221,10 @@ def main():
     # never sit in front of K7's on a CU (256 MiB: decode stage 0.150 -> 0.141 ms)
     main = torch.cuda.Stream(priority=-1)
     torch.cuda.set_stream(main)
-    DEPTH = 3
+    # Steps in flight.  Steady state needs three (K2 of step i+2 behind K5/K7 of step i); eight let the main stream count the
+    # first seven inputs while the FIRST step's one-wave code build (0.37 ms, nothing to overlap it with at the start of a
+    # run) is still going: at 20 timed steps that start-up is 0.04 ms per step, at 200 it does not show.
+    DEPTH = int(os.environ.get("GHF_BENCH_DEPTH", "8"))
     ahead = DEPTH - 1
     NSIDE = int(os.environ.get("GHF_BENCH_NSIDE", "2"))
     sides = [torch.cuda.Stream(priority=0) for _ in range(NSIDE)]
@@ -386,7 +389,7 @@ def main():
                        "bytes_per_gpu": n, "compressed_bytes_per_gpu": comp_bytes, "parallelism": "shard%d" % world,
                        "collectives": "none" if world == 1 else "all_reduce(256 x i64) + all_gather(1 x i64) per step",
                        "world_size": world, "collective_path": coll_path, "backend": ("none" if world == 1 else ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (rehearsal)")),
-                       "pipeline": "steps software-pipelined, 3 in flight (one ghf context and one side stream each): main stream = histogram of step i+2, emit + decode of step i; side streams, two steps ahead = histogram all-reduce, one-wave code build, chunk pricing, decode tables, offset all-gather"},
+                       "pipeline": "steps software-pipelined, up to %d in flight (one ghf context each, two side streams): main stream = histogram of step i+%d, emit + decode of step i; side streams, ahead of the main one = histogram all-reduce, one-wave code build, chunk pricing, decode tables, offset all-gather" % (DEPTH, DEPTH - 1)},
             "encode_GBps": round(n * world / (enc_ms * 1e-3) / 1e9, 3), "decode_GBps": round(n * world / (stage_ms["decode"] * 1e-3) / 1e9, 3),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
