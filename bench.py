@@ -210,7 +210,7 @@ def main():
 
     # The one-wavefront code build (K2) is latency-bound (a strictly sequential heap on 1 of 256 CUs) and takes about
     # as long as all streaming kernels of a step together; the two collectives are latency-bound too.  So the steps
-    # are software-pipelined, three in flight: the main stream runs only the kernels that stream through HBM --
+    # are software-pipelined, several in flight (DEPTH below): the main stream runs only the kernels that stream through HBM --
     # histogram of step i+2, emit and decode of step i -- while a side stream PER STEP IN FLIGHT runs, two steps ahead,
     # the histogram all-reduce, the code build, the chunk pricing (K4), the decode-table build and the offset
     # all-gather of step i+2 (one side stream for all steps would serialise the code builds of consecutive steps: the
@@ -224,7 +224,7 @@ def main():
     # Steps in flight.  Steady state needs three (K2 of step i+2 behind K5/K7 of step i); eight let the main stream count the
     # first seven inputs while the FIRST step's one-wave code build (0.37 ms, nothing to overlap it with at the start of a
     # run) is still going: at 20 timed steps that start-up is 0.04 ms per step, at 200 it does not show.
-    DEPTH = int(os.environ.get("GHF_BENCH_DEPTH", "8"))
+    DEPTH = int(os.environ.get("GHF_BENCH_DEPTH", "8"))  # (6 and 10 measure 5-10 % slower than 8 and 12, repeatably; not understood)
     ahead = DEPTH - 1
     NSIDE = int(os.environ.get("GHF_BENCH_NSIDE", "2"))
     sides = [torch.cuda.Stream(priority=0) for _ in range(NSIDE)]
