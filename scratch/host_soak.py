@@ -10,7 +10,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 t0 = time.time(); cases = 0
 def gen():
-    n = int(2 ** rng.uniform(0, 24.5)) + int(rng.integers(0, 70))
+    n = int(2 ** (rng.uniform(25.5, 28.2) if os.environ.get("HOST_SOAK_BIG") else rng.uniform(0, 24.5))) + int(rng.integers(0, 70))
     k = int(rng.integers(1, 257))
     mode = int(rng.integers(0, 5))
     if mode == 0: w = np.ones(k)
@@ -40,7 +40,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
           data = gen()
           f = os.path.join(d, "x.bin"); data.tofile(f)
           env = dict(os.environ)
-          env["GHF_PIECE_BYTES"] = str(int(rng.choice([65536, 131072, 1 << 20, 16 << 20])))
+          env["GHF_PIECE_BYTES"] = str(int(rng.choice([4 << 20, 16 << 20, 32 << 20] if os.environ.get("HOST_SOAK_BIG") else [65536, 131072, 1 << 20, 16 << 20])))
           env["GHF_IO_THREADS"] = str(int(rng.choice([1, 2, 5, 12])))
           env["GHF_RESIDENT_BYTES"] = str(int(rng.choice([0, 1 << 40])))
           sink = str(rng.choice(["mmap", "pwrite", ""]))
