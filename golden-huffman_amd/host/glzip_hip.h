@@ -488,6 +488,9 @@ class Pipe {
   void reserve_all(size_t bytes) { (void)reserve(bytes, true); }
   // an operation failed half-way: nothing more is written, the mapping goes, the file is emptied
   void abandon_sink() {
+    pre_stop_ = true;  // (nothing may go on making pages for a file that is about to be emptied and closed)
+    pre_job_.drop();
+    pre_fd_ = -1;
     for (size_t i = 0; i < out_ring_.size(); ++i) out_ring_[i].job.drop();
     landing_.clear();
     unmap_.drop();
