@@ -63,3 +63,19 @@ def test_reference_framework_templates_accept_the_hip_policies(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     assert subprocess.run([str(exe)]).returncode == 0  # no arguments: no GPU work
+
+
+def test_host_layer_compiles_warning_free(tmp_path):
+    """the C++ host layer (header-only, plain g++, no HIP headers) and its tool build with -Wall -Wextra -Werror"""
+    import pkgload
+
+    pkg = pkgload.load()
+    if not os.path.exists(pkg.ghf.LIB_PATH):
+        pkg.build()
+    host = os.path.join(ROOT, "golden-huffman_amd", "host")
+    exe = tmp_path / "ghf_tool"
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-pthread", "-I" + ROOT + "/include", "-I" + host,
+           os.path.join(host, "ghf_tool.cc"), "-o", str(exe), "-L" + os.path.dirname(pkg.ghf.LIB_PATH), "-lghf",
+           "-Wl,-rpath," + os.path.dirname(pkg.ghf.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
