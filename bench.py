@@ -11,6 +11,11 @@ resident in HBM before the timed region.  N=1: BASELINE config 2 (256 MiB unifor
 N>1: every rank holds a 4 GiB shard of one N x 4 GiB stream (weak scaling; N = 8 is BASELINE config 4: 32 GiB);
 one global code via an RCCL all-reduce of the 256-bin histogram and an all-gather of the per-rank bit totals.
 
+Steps in flight work on DIFFERENT buffers: GHF_BENCH_SETS (default 3) sets of {input, output, decoded, side-car}, each with
+its own synthetic data, rotate with the step number.  A watchdog thread ends the run with the name of the stuck stage when
+no stage completes for GHF_BENCH_STEP_TIMEOUT seconds (default 120) -- a collective that never returns must not sit there
+until the driver's limit.
+
 Rank 0 prints ONE JSON line.  `value` = input GB (1e9 B) pushed through encode+decode per second by the
 whole job.  `roofline` prices the dominant kernel against HBM peak; `cpu_baseline` is the reference's
 own code (oracle/_ref, built from /root/reference in the build container) timed on this host, pinned to one
@@ -97,17 +102,27 @@ def cpu_baseline(data_host, kind):
             "host_cores": os.cpu_count(), "pinned_core": core}
 
 
-def copy_probe(torch, a, b, reps=5):
-    """what a plain device-to-device copy of the same bytes reaches on this box (context for the roofline)"""
+def _time_gbps(torch, fn, nbytes, reps):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    b.copy_(a)
+    fn()
     e0.record()
     for _ in range(reps):
-        b.copy_(a)
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    return 2.0 * a.numel() * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def copy_probe(torch, ctx, a, b, reps=5):
+    """what a kernel that only MOVES the same bytes reaches on this box (context for the roofline): the library's own streaming
+    copy kernel (ghf_copy_d2d: 16 B per lane, four loads in flight, non-temporal hints -- the access shape of K1/K5/K7), and
+    torch's copy_ beside it.  GB/s of read + write."""
+    ctx.use_current_stream()
+    n = a.numel() & ~15
+    return {"copy_probe_GBps": round(_time_gbps(torch, lambda: ctx.copy_d2d(b, a, n, non_temporal=True), 2.0 * n, reps), 1),
+            "copy_probe_plain_GBps": round(_time_gbps(torch, lambda: ctx.copy_d2d(b, a, n, non_temporal=False), 2.0 * n, reps), 1),
+            "torch_copy_GBps": round(_time_gbps(torch, lambda: b.copy_(a), 2.0 * a.numel(), reps), 1)}
 
 
 def full_size_config(torch, ghf, synth, ctx, kind, mib, reps=5):
@@ -147,7 +162,8 @@ def full_size_config(torch, ghf, synth, ctx, kind, mib, reps=5):
     t_dec = timed(dec_once)
     ctx.sync()
     ok = bool((dec[:n] == d_in).all().item())
-    probe = copy_probe(torch, d_in, dec, 3)
+    probes = copy_probe(torch, ctx, d_in, dec, 3)
+    probe = probes["copy_probe_GBps"]
     ctx.index_free(idx)
     enc_ms = t_hist + t_plan + t_emit  # the streaming part of encode (the one-wave code build does not scale with n)
     res = {
@@ -159,11 +175,59 @@ def full_size_config(torch, ghf, synth, ctx, kind, mib, reps=5):
                    "ms_at_copy_rate": round((2 * n + c) / (probe * 1e9) * 1e3, 4)},
         "decode": {"algorithmic_GBps": round((c + n) / (t_dec * 1e-3) / 1e9, 1), "frac_of_8TBps": round((c + n) / (t_dec * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                    "output_GBps": round(n / (t_dec * 1e-3) / 1e9, 1), "ms_at_copy_rate": round((c + n) / (probe * 1e9) * 1e3, 4)},
-        "copy_probe_GBps": round(probe, 1),
+        "single_buffer_ms": round(t_hist + t_code + t_plan + t_emit + t_dec, 4),
     }
+    res.update(probes)
     del d_in, out, dec
     torch.cuda.empty_cache()
     return res
+
+
+class Watchdog:
+    """Ends the process with the name of the stuck stage when nothing completes for `timeout` seconds.  The main thread
+    notes what it is about to queue (`enter`) and leaves an event behind every stage (`mark`); a daemon thread looks at
+    the oldest event that has not completed yet.  It never touches the GPU except through event.query()."""
+
+    def __init__(self, timeout, rank):
+        import threading
+
+        self.timeout, self.rank = timeout, rank
+        self.pending = []  # (label, event, t_recorded), oldest first
+        self.host = ("start", time.monotonic())
+        self.lock = threading.Lock()
+        self.stop = False
+        self.t = threading.Thread(target=self._run, daemon=True)
+        if timeout > 0:
+            self.t.start()
+
+    def enter(self, label):
+        self.host = (label, time.monotonic())
+
+    def mark(self, label, event):
+        if self.timeout > 0:
+            with self.lock:
+                self.pending.append((label, event, time.monotonic()))
+
+    def close(self):
+        self.stop = True
+
+    def _fire(self, why):
+        sys.stderr.write("bench.py: rank %d: no progress for %.0f s -- %s\n" % (self.rank, self.timeout, why))
+        sys.stderr.flush()
+        os._exit(3)  # (exit, never exec: the GPU is initialised)
+
+    def _run(self):
+        while not self.stop:
+            time.sleep(0.25)
+            now = time.monotonic()
+            with self.lock:
+                while self.pending and self.pending[0][1].query():
+                    self.pending.pop(0)
+                oldest = self.pending[0] if self.pending else None
+            if oldest is not None and now - oldest[2] > self.timeout:
+                self._fire("the GPU has not finished stage '%s' (queued %.0f s ago); the host is at '%s'" % (oldest[0], now - oldest[2], self.host[0]))
+            if oldest is None and now - self.host[1] > self.timeout and self.host[0] not in ("done", "start"):
+                self._fire("the host is stuck in '%s'" % self.host[0])
 
 
 def main():
@@ -184,49 +248,66 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
+        import datetime
+
         import torch.distributed as dist
 
+        tmo = datetime.timedelta(seconds=int(os.environ.get("GHF_BENCH_PG_TIMEOUT", "300")))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
     pkg = pkgload.load()
     ghf = pkg.ghf
     from golden_huffman_amd import synth
 
+    wd = Watchdog(float(os.environ.get("GHF_BENCH_STEP_TIMEOUT", "120")), rank)
+    hang_at = os.environ.get("GHF_BENCH_INJECT_HANG", "")  # "<rank>:<step>": that rank never joins that step's all-reduce (tests)
     ctx = ghf.Context(local_rank)
     n = args.mib << 20
-    d_in = synth.make(torch, args.kind, n, offset=rank * n, device="cuda")
     bound = ghf.compress_bound(n) if world == 1 else ghf.shard_bound(n)
-    out = ctx.empty_u8(bound)
-    dec = ctx.empty_u8(n)
-    index = ctx.index_alloc(n)
-    index.flags = 0 if rank == world - 1 else ghf.INDEX_NO_END_MARK  # only the last shard ends with the end mark
+    # Buffer sets: steps in flight work on different inputs and write different outputs.  Set s of rank r is the byte range
+    # [(s * world + r) * n, +n) of one long synthetic stream, so that (for every s) the ranks' shards are consecutive.
+    NSETS = max(1, int(os.environ.get("GHF_BENCH_SETS", "3")))
+
+    class BufSet:
+        pass
+
+    sets = []
+    for si in range(NSETS):
+        b = BufSet()
+        b.d_in = synth.make(torch, args.kind, n, offset=(si * world + rank) * n, device="cuda")
+        b.out = ctx.empty_u8(bound)
+        b.dec = ctx.empty_u8(n)
+        b.index = ctx.index_alloc(n)
+        b.index.flags = 0 if rank == world - 1 else ghf.INDEX_NO_END_MARK  # only the last shard ends with the end mark
+        b.end = torch.empty(2, dtype=torch.int64, device="cuda")
+        sets.append(b)
     torch.cuda.synchronize()
 
     names = ["histogram", "allreduce", "build_code", "header", "plan", "allgather", "emit", "decode"]
-    acc_ms = {k: 0.0 for k in names}
-    ev_log = []  # (name, start_event, end_event)
 
-    # The one-wavefront code build (K2) is latency-bound (a strictly sequential heap on 1 of 256 CUs) and takes about
-    # as long as all streaming kernels of a step together; the two collectives are latency-bound too.  So the steps
-    # are software-pipelined, several in flight (DEPTH below): the main stream runs only the kernels that stream through HBM --
-    # histogram of step i+2, emit and decode of step i -- while a side stream PER STEP IN FLIGHT runs, two steps ahead,
-    # the histogram all-reduce, the code build, the chunk pricing (K4), the decode-table build and the offset
-    # all-gather of step i+2 (one side stream for all steps would serialise the code builds of consecutive steps: the
-    # 0.34 ms one-wave kernel then paces the whole pipeline).  Each step in flight has its own ghf context (= its own
-    # workspace: the per-chunk histogram K1 leaves for K4, the chunk offsets K4 leaves for K5), which is also what
-    # pipelining over DIFFERENT input buffers needs.  Every step does all of its work inside the timed region.
-    # the streaming kernels run on a high-priority stream, the latency-bound helpers on normal ones: a helper's waves then
-    # never sit in front of K7's on a CU (256 MiB: decode stage 0.150 -> 0.141 ms)
+    # The one-wavefront code build (K2) is latency-bound (a strictly sequential heap on 1 of 256 CUs) and the two
+    # collectives are latency-bound too.  So the steps are software-pipelined, several in flight (DEPTH below): the main
+    # stream runs only the kernels that stream through HBM -- histogram of step i+DEPTH-1, emit and decode of step i --
+    # while side streams run, ahead of it, the histogram all-reduce, the code build, the chunk pricing (K4), the
+    # decode-table build and the offset all-gather.  Each step in flight has its own ghf context (= its own workspace:
+    # the per-chunk histogram K1 leaves for K4, the chunk offsets K4 leaves for K5) and works on buffer set i % NSETS.
+    # Every step does all of its work inside the timed region.
+    # The streaming kernels run on a high-priority stream, the latency-bound helpers on normal ones: a helper's waves then
+    # never sit in front of K7's on a CU (256 MiB: decode stage 0.150 -> 0.141 ms).
     main = torch.cuda.Stream(priority=-1)
     torch.cuda.set_stream(main)
-    # Steps in flight.  Steady state needs three (K2 of step i+2 behind K5/K7 of step i); eight let the main stream count the
-    # first seven inputs while the FIRST step's one-wave code build (0.37 ms, nothing to overlap it with at the start of a
-    # run) is still going: at 20 timed steps that start-up is 0.04 ms per step, at 200 it does not show.
-    DEPTH = int(os.environ.get("GHF_BENCH_DEPTH", "8"))  # (6 and 10 measure 5-10 % slower than 8 and 12, repeatably; not understood)
+    # Steps in flight.  Steady state needs three; more let the main stream count the first inputs while the FIRST step's
+    # one-wave code build (nothing to overlap it with at the start of a run) is still going.
+    DEPTH = int(os.environ.get("GHF_BENCH_DEPTH", "8"))
     ahead = DEPTH - 1
-    NSIDE = int(os.environ.get("GHF_BENCH_NSIDE", "2"))
+    # Side streams.  N = 1: two (one would serialise the code builds of consecutive steps: that one-wave kernel then paces
+    # the pipeline).  N > 1: ONE, and one communicator -- collectives are then issued in strict step order on one stream on
+    # every rank, which is the only order RCCL guarantees to match up across ranks (two communicators' kernels may be
+    # launched in different orders on different ranks: a deadlock that needs all 8 GPUs to show).  GHF_BENCH_NSIDE
+    # overrides (one communicator per side stream).
+    NSIDE = int(os.environ.get("GHF_BENCH_NSIDE", "2" if world == 1 else "1"))
     sides = [torch.cuda.Stream(priority=0) for _ in range(NSIDE)]
     ctxs = [ctx] + [ghf.Context(local_rank) for _ in range(DEPTH - 1)]
     hists = [torch.empty(ghf.NSYM, dtype=torch.int64, device="cuda") for _ in range(DEPTH)]
@@ -236,26 +317,10 @@ def main():
     t_start = [torch.empty(1, dtype=torch.int64, device="cuda") for _ in range(DEPTH)]
     ev_hist = [torch.cuda.Event() for _ in range(DEPTH)]
     ev_ready = [torch.cuda.Event() for _ in range(DEPTH)]
-    t_end = torch.empty(2, dtype=torch.int64, device="cuda")
     t_nbytes = torch.empty(1, dtype=torch.int64, device="cuda")
     last_rank = rank == world - 1
-    emit_flags = (ghf.EMIT_LAST if last_rank else 0) | (ghf.EMIT_REBASE if rank > 0 else ghf.EMIT_HEADER)  # rank 0 writes the header
-
-    # N > 1: the two exchanges go through the C ABI (ghf_comm_*: RCCL called directly, queued on the step's side stream);
-    # torch.distributed only carries the 128-byte ncclUniqueId.  One communicator per side stream.  If that cannot be set
-    # up (or GHF_BENCH_COLLECTIVES=torch), torch.distributed's own collectives on the same stream are used instead.
-    comms, coll_path = None, "none"
-    if world > 1:
-        coll_path = "torch.distributed (%s)" % args.backend
-        if args.backend == "nccl" and os.environ.get("GHF_BENCH_COLLECTIVES", "cabi") == "cabi":
-            try:
-                ids = [ghf.comm_unique_id() if rank == 0 else None for _ in range(NSIDE)]
-                dist.broadcast_object_list(ids, src=0)
-                comms = [ctx.comm_init(ids[j], world, rank) for j in range(NSIDE)]
-                coll_path = "C ABI: ghf_comm_allreduce_hist / ghf_comm_allgather_total (RCCL %s called directly)" % ghf.rccl_version()
-            except Exception as e:
-                comms = None
-                coll_path += " [C-ABI communicator failed: %s]" % repr(e)[:120]
+    sharded_flags = (ghf.EMIT_LAST if last_rank else 0) | (ghf.EMIT_REBASE if rank > 0 else ghf.EMIT_HEADER)  # rank 0 writes the header
+    local_flags = ghf.EMIT_LAST | ghf.EMIT_HEADER
 
     def all_reduce_sum(t):
         if args.backend == "nccl":
@@ -273,98 +338,184 @@ def main():
             dist.all_gather(parts, t.cpu())
             out_t.copy_(torch.cat(parts))
 
-    def timed(name, record, stream, fn):
-        if not record:
-            return fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        r = fn()
-        e1.record(stream)
-        ev_log.append((name, e0, e1))
-        return r
+    class Run:
+        """one pipelined run of K steps.  sharded = False: every rank for itself (no collectives, the shard is a whole stream)."""
 
-    def front(i, record):
-        """step i up to the point where its emit can start: K1 on the main stream; all-reduce, K2/K3, K4, decode tables,
-        all-gather on this step's side stream."""
-        k = i % DEPTH
-        cx, h, c, side = ctxs[k], hists[k], codes[k], sides[i % NSIDE]
-        cx.use_stream(main)
-        timed("histogram", record, main, lambda: cx.histogram(d_in, out=h))
-        ev_hist[k].record(main)
-        side.wait_event(ev_hist[k])
-        cx.use_stream(side)
-        if world > 1:
-            if comms:
-                timed("allreduce", record, side, lambda: cx.comm_allreduce_hist(comms[i % NSIDE], h))
+        def __init__(self, sharded, comms):
+            self.sharded, self.comms = sharded, comms
+            self.ev_log = []  # (name, start_event, end_event)
+
+        def timed(self, name, step, record, stream, fn):
+            wd.enter("%s of step %d" % (name, step))
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                r = fn()
+                e1.record(stream)
+                self.ev_log.append((name, e0, e1))
             else:
-                with torch.cuda.stream(side):
-                    timed("allreduce", record, side, lambda: all_reduce_sum(h[:256]))
-        timed("build_code", record, side, lambda: cx.build_code(h, c))
-        timed("plan", record, side, lambda: cx.encode_plan(d_in, c, total=t_total[k]))
-        cx.decode_prepare(c)  # the decode tables of this code: one tiny kernel less on the main stream
-        if world > 1:
-            def gather():
-                if comms:
-                    cx.comm_allgather_total(comms[i % NSIDE], t_total[k], t_totals[k])
+                r = fn()
+                e1 = None
+            if name in ("allreduce", "allgather", "decode"):  # what the watchdog looks at: the collectives and every step's end
+                if e1 is None:
+                    e1 = torch.cuda.Event()
+                    e1.record(stream)
+                wd.mark("%s of step %d" % (name, step), e1)
+            return r
+
+        def front(self, i, record):
+            """step i up to the point where its emit can start: K1 on the main stream; all-reduce, K2/K3, K4, decode
+            tables, all-gather on a side stream."""
+            k = i % DEPTH
+            cx, h, c, side, b = ctxs[k], hists[k], codes[k], sides[i % NSIDE], sets[i % NSETS]
+            comm = self.comms[i % NSIDE] if self.comms else None
+            cx.use_stream(main)
+            self.timed("histogram", i, record, main, lambda: cx.histogram(b.d_in, out=h))
+            ev_hist[k].record(main)
+            side.wait_event(ev_hist[k])
+            cx.use_stream(side)
+            if self.sharded:
+                if hang_at == "%d:%d" % (rank, i):
+                    wd.enter("allreduce of step %d (GHF_BENCH_INJECT_HANG: this rank stays away)" % i)
+                    time.sleep(1e6)
+                if comm:
+                    self.timed("allreduce", i, record, side, lambda: cx.comm_allreduce_hist(comm, h))
                 else:
                     with torch.cuda.stream(side):
-                        all_gather_1(t_totals[k], t_total[k])
-                cx.shard_start_bit(c, t_totals[k], world, rank, out=t_start[k])
-            timed("allgather", record, side, gather)
-        ev_ready[k].record(side)
+                        self.timed("allreduce", i, record, side, lambda: all_reduce_sum(h[:256]))
+            self.timed("build_code", i, record, side, lambda: cx.build_code(h, c))
+            self.timed("plan", i, record, side, lambda: cx.encode_plan(b.d_in, c, total=t_total[k]))
+            cx.decode_prepare(c)  # the decode tables of this code: one tiny kernel less on the main stream
+            if self.sharded:
+                def gather():
+                    if comm:
+                        cx.comm_allgather_total(comm, t_total[k], t_totals[k])
+                    else:
+                        with torch.cuda.stream(side):
+                            all_gather_1(t_totals[k], t_total[k])
+                    cx.shard_start_bit(c, t_totals[k], world, rank, out=t_start[k])
+                self.timed("allgather", i, record, side, gather)
+            ev_ready[k].record(side)
 
-    def run(K, record):
-        end = None
-        rec_of = lambda j: record and (j % 4 == 1 or K <= 4)  # events on every 4th step: keeps the host ahead of the GPU
-        for j in range(min(ahead, K)):
-            front(j, rec_of(j))
-        for i in range(K):
-            k = i % DEPTH
-            cx, c = ctxs[k], codes[k]
-            if i + ahead < K:
-                front(i + ahead, rec_of(i + ahead))  # (uses the events of slot (i + 2) % 3, not this step's)
-            main.wait_event(ev_ready[k])
-            cx.use_stream(main)
-            start_bit = t_start[k] if world > 1 else None
-            end = timed("emit", rec_of(i), main, lambda: cx.encode_emit(d_in, c, out, start_bit=start_bit, flags=emit_flags, index=index, end=t_end))
-            timed("decode", rec_of(i), main, lambda: cx.decode(out, bound, c, index, d_out=dec, nbytes=t_nbytes))
-        return end
+        def run(self, K, record):
+            rec_of = lambda j: record and (j % 4 == 1 or K <= 4)  # events on every 4th step: keeps the host ahead of the GPU
+            for j in range(min(ahead, K)):
+                self.front(j, rec_of(j))
+            for i in range(K):
+                k = i % DEPTH
+                cx, c, b = ctxs[k], codes[k], sets[i % NSETS]
+                if i + ahead < K:
+                    self.front(i + ahead, rec_of(i + ahead))
+                main.wait_event(ev_ready[k])
+                cx.use_stream(main)
+                start_bit = t_start[k] if self.sharded else None
+                flags = sharded_flags if self.sharded else local_flags
+                b.index.flags = (0 if last_rank else ghf.INDEX_NO_END_MARK) if self.sharded else 0
+                self.timed("emit", i, rec_of(i), main, lambda: cx.encode_emit(b.d_in, c, b.out, start_bit=start_bit, flags=flags, index=b.index, end=b.end))
+                self.timed("decode", i, rec_of(i), main, lambda: cx.decode(b.out, bound, c, b.index, d_out=b.dec, nbytes=t_nbytes))
 
-    end = run(max(args.warmup, 1), False)
-    torch.cuda.synchronize()
-    for cx in ctxs:
-        cx.sync()
-    if not args.no_verify:
-        assert bool((dec[:n] == d_in).all().item()), "round trip mismatch"
-    comp_bytes = int(end[1].item())
+        def measure(self, K, barrier):
+            """time exactly K steps: barrier + synchronize on both sides"""
+            if barrier:
+                wd.enter("barrier before the timed region")
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self.run(K, True)
+            wd.enter("synchronize after the timed region")
+            torch.cuda.synchronize()
+            if barrier:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            for cx in ctxs:
+                cx.sync()  # raises if any stage latched an error
+            return elapsed
 
+        def stage_ms(self):
+            acc, cnt = {k: 0.0 for k in names}, {k: 0 for k in names}
+            for name, e0, e1 in self.ev_log:
+                acc[name] += e0.elapsed_time(e1)
+                cnt[name] += 1
+            return {k: (acc[k] / cnt[k] if cnt[k] else 0.0) for k in names}
+
+    def verify_sets(what):
+        torch.cuda.synchronize()
+        for cx in ctxs:
+            cx.sync()
+        if not args.no_verify:
+            for si, b in enumerate(sets):
+                assert bool((b.dec[:n] == b.d_in).all().item()), "round trip mismatch (%s, buffer set %d)" % (what, si)
+
+    extra = {}
+    # ---- N > 1, before any communicator exists: the SAME shard on this GPU alone, same pipeline, no collectives.  The
+    # speed-up of the N-GPU run is quoted against this number (same bytes per GPU), never against the 256 MiB N = 1 line.
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps, True)
-    torch.cuda.synchronize()
+        solo = Run(False, None)
+        solo.run(NSETS, False)
+        verify_sets("same shard, this GPU alone")
+        ks = max(4, min(args.steps, 10))
+        t_solo = solo.measure(ks, False)
+        extra["same_shard_1gpu_ms_per_step"] = round(t_solo * 1e3 / ks, 4)
+        extra["same_shard_1gpu_steps"] = ks
+        extra["same_shard_1gpu_GBps"] = round(n * ks / t_solo / 1e9, 3)
+
+    # N > 1: the two exchanges go through the C ABI (ghf_comm_*: RCCL called directly, queued on the step's side stream);
+    # torch.distributed only carries the 128-byte ncclUniqueId.  If that cannot be set up (or GHF_BENCH_COLLECTIVES=torch),
+    # torch.distributed's own collectives on the same stream are used instead.
+    comms, coll_path = None, "none"
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    for cx in ctxs:
-        cx.sync()  # raises if any stage latched an error
+        coll_path = "torch.distributed (%s)" % args.backend
+        if args.backend == "nccl" and os.environ.get("GHF_BENCH_COLLECTIVES", "cabi") == "cabi":
+            try:
+                wd.enter("communicator set-up")
+                ids = [ghf.comm_unique_id() if rank == 0 else None for _ in range(NSIDE)]
+                dist.broadcast_object_list(ids, src=0)
+                comms = [ctx.comm_init(ids[j], world, rank) for j in range(NSIDE)]
+                coll_path = "C ABI: ghf_comm_allreduce_hist / ghf_comm_allgather_total (RCCL %s called directly)" % ghf.rccl_version()
+            except Exception as e:
+                comms = None
+                coll_path += " [C-ABI communicator failed: %s]" % repr(e)[:120]
+
+    job = Run(world > 1, comms)
+    job.run(NSETS, False)  # every buffer set once, verified (not part of --warmup)
+    verify_sets("sharded pipeline" if world > 1 else "pipeline")
+    if world > 1 and comms:
+        # one step through the ONE-CALL entry point (ghf_encode_sharded: K1 -> all-reduce -> K2/K3 -> K4 -> all-gather -> K5 on
+        # one stream): its bytes must equal what the staged calls above wrote for the same shard, and decode back
+        wd.enter("ghf_encode_sharded (verified step)")
+        b = sets[0]
+        ctx.use_stream(main)
+        alt, aidx = ctx.empty_u8(bound), ctx.index_alloc(n)
+        r = ctx.encode_sharded(comms[0], b.d_in, d_out=alt, index=aidx)
+        torch.cuda.synchronize()
+        ctx.sync()
+        nb = int(r["end"][1].item())
+        same = nb == int(b.end[1].item()) and bool((alt[:nb] == b.out[:nb]).all().item())
+        back, _ = ctx.decode(alt, bound, r["code"], aidx)
+        ctx.sync()
+        ok = same and bool((back[:n] == b.d_in).all().item())
+        extra["encode_sharded_c_abi"] = {"bytes_equal_staged_pipeline": bool(same), "round_trip_ok": bool(ok), "shard_bytes": nb}
+        assert ok or args.no_verify, "ghf_encode_sharded differs from the staged pipeline on rank %d" % rank
+        ctx.index_free(aidx)
+        del alt, back
+    job.run(max(args.warmup, 1), False)
+    verify_sets("warm-up")
+    comp_bytes = int(sets[(max(args.warmup, 1) - 1) % NSETS].end[1].item())
+
+    elapsed = job.measure(args.steps, world > 1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    counts = {k: 0 for k in names}
-    for name, e0, e1 in ev_log:
-        acc_ms[name] += e0.elapsed_time(e1)
-        counts[name] += 1
-    stage_ms = {k: (acc_ms[k] / counts[k] if counts[k] else 0.0) for k in names}
+    stage_ms = job.stage_ms()
+    wd.enter("done")
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         total_in = n * world
         value = total_in * args.steps / elapsed / 1e9
-        enc_ms = sum(stage_ms[k] for k in names[:7])  # un-overlapped sum of the encode stages (latency of one buffer)
+        enc_ms = sum(stage_ms[k] for k in names[:7])  # un-overlapped sum of the encode stages
         # roofline of the dominant kernel (algorithmic bytes, SURVEY 8d): emit reads N and writes the body,
         # decode reads C and writes N, histogram reads N
         cand = {"k_emit": (n + comp_bytes, stage_ms["emit"]), "k_decode": (comp_bytes + n, stage_ms["decode"]),
@@ -378,7 +529,7 @@ def main():
                 traffic = json.load(open(tf)).get("%s_%s_%dMiB" % (dom, args.kind, args.mib))
             except Exception:
                 traffic = None
-        copy_gbps = copy_probe(torch, d_in, dec)
+        probes = copy_probe(torch, ctx, sets[0].d_in, sets[0].dec)
         cfg4 = world > 1 and args.kind == "uniform" and args.mib == 4096
         res = {
             "metric": "encode+decode GB/s (input bytes)", "value": round(value, 3), "unit": "GB/s", "n_gpus": world,
@@ -389,33 +540,60 @@ def main():
                        "bytes_per_gpu": n, "compressed_bytes_per_gpu": comp_bytes, "parallelism": "shard%d" % world,
                        "collectives": "none" if world == 1 else "all_reduce(256 x i64) + all_gather(1 x i64) per step",
                        "world_size": world, "collective_path": coll_path, "backend": ("none" if world == 1 else ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (rehearsal)")),
-                       "pipeline": "steps software-pipelined, up to %d in flight (one ghf context each, two side streams): main stream = histogram of step i+%d, emit + decode of step i; side streams, ahead of the main one = histogram all-reduce, one-wave code build, chunk pricing, decode tables, offset all-gather" % (DEPTH, DEPTH - 1)},
+                       "buffer_sets": NSETS, "side_streams": NSIDE, "communicators": len(comms) if comms else 0,
+                       "pipeline": "steps software-pipelined, up to %d in flight (one ghf context each, %d side stream(s)), rotating over %d sets of {input, output, decoded, side-car} buffers: main stream = histogram of step i+%d, emit + decode of step i; side stream(s), ahead of the main one = histogram all-reduce, one-wave code build, chunk pricing, decode tables, offset all-gather" % (DEPTH, NSIDE, NSETS, DEPTH - 1)},
             "encode_GBps": round(n * world / (enc_ms * 1e-3) / 1e9, 3), "decode_GBps": round(n * world / (stage_ms["decode"] * 1e-3) / 1e9, 3),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": cand[dom][0], "avg_launch_ms": round(cand[dom][1], 4),
-                         "copy_probe_GBps": round(copy_gbps, 1),
                          "all_kernels": {k: {"achieved": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
                                          for k, v in cand.items() if v[1] > 0}},
             "library": ghf.lib_identity(),
         }
+        res["roofline"].update(probes)
+        res.update(extra)
+        if "same_shard_1gpu_ms_per_step" in extra:
+            res["speedup_vs_same_shard"] = round(world * extra["same_shard_1gpu_ms_per_step"] / ms_per_step, 3)
         if world == 1:
+            # ONE buffer, nothing overlapped: every stage of encode + decode back to back on one stream (the latency a caller
+            # with a single buffer sees; `value` above is the throughput of the pipelined job)
+            cx, b = ctxs[0], sets[0]
+            cx.use_stream(main)
+
+            def one_buffer():
+                cx.histogram(b.d_in, out=hists[0])
+                cx.build_code(hists[0], codes[0])
+                cx.encode_plan(b.d_in, codes[0], total=t_total[0])
+                cx.decode_prepare(codes[0])
+                cx.encode_emit(b.d_in, codes[0], b.out, flags=local_flags, index=b.index, end=b.end)
+                cx.decode(b.out, bound, codes[0], b.index, d_out=b.dec, nbytes=t_nbytes)
+
+            one_buffer()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10
+            e0.record(main)
+            for _ in range(reps):
+                one_buffer()
+            e1.record(main)
+            torch.cuda.synchronize()
+            cx.sync()
+            res["single_buffer_ms"] = round(e0.elapsed_time(e1) / reps, 4)
+            res["single_buffer_GBps"] = round(n / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9, 3)
             # the decode path a stream WITHOUT side-car takes (a .crs2 the reference wrote; what Decompressor<...>::decompress()
             # of the C++ host layer runs): K6 rebuilds the side-car on the GPU, then K7.  Host wall time: K6 looks at a
             # convergence word from the host a few times.
-            cx = ctxs[0]
-            cx.use_stream(main)
-            cx.decode(out, comp_bytes, codes[0], None, d_out=dec, cap=n, nbytes=t_nbytes)
+            cx.decode(b.out, comp_bytes, codes[0], None, d_out=b.dec, cap=n, nbytes=t_nbytes)
             torch.cuda.synchronize()
             reps = 5
             tf0 = time.perf_counter()
             for _ in range(reps):
-                cx.decode(out, comp_bytes, codes[0], None, d_out=dec, cap=n, nbytes=t_nbytes)
+                cx.decode(b.out, comp_bytes, codes[0], None, d_out=b.dec, cap=n, nbytes=t_nbytes)
             torch.cuda.synchronize()
             tf = (time.perf_counter() - tf0) / reps
             cx.sync()
-            ok_f = int(t_nbytes.item()) == n and (args.no_verify or bool((dec[:n] == d_in).all().item()))
+            ok_f = int(t_nbytes.item()) == n and (args.no_verify or bool((b.dec[:n] == b.d_in).all().item()))
             res["decode_foreign"] = {"GBps": round(n / tf / 1e9, 3), "ms": round(tf * 1e3, 4), "round_trip_ok": bool(ok_f),
                                      "vs_indexed_decode": round(tf * 1e3 / stage_ms["decode"], 2) if stage_ms["decode"] else None,
                                      "what": "ghf_decode(index = NULL): K6 side-car reconstruction + K7, host wall time per stream"}
@@ -427,7 +605,11 @@ def main():
         if world == 1 and not args.no_configs:
             # the other single-GPU BASELINE configs at full size: 4 GiB uniform (north star: encode read side), configs[2]
             # (4 GiB Zipf encode) and configs[4] (4 GiB 16-symbol decode); every number has its stage times beside it
-            del out, dec
+            host_in = sets[0].d_in.cpu().numpy() if not args.no_cpu_baseline else None
+            for b in sets:
+                ctx.index_free(b.index)
+                b.index = None
+                del b.d_in, b.out, b.dec
             torch.cuda.empty_cache()
             blk = {}
             for key, kind in (("uniform_4GiB", "uniform"), ("configs[2]_zipf_4GiB", "zipf"), ("configs[4]_sym16_4GiB", "sym16")):
@@ -436,10 +618,15 @@ def main():
                 except Exception as e:  # (e.g. not enough free HBM on a shared box)
                     blk[key] = {"error": repr(e)[:200]}
             res["configs"] = blk
+        else:
+            host_in = sets[0].d_in.cpu().numpy() if (world == 1 and not args.no_cpu_baseline) else None
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(d_in.cpu().numpy(), args.kind)
+            res["cpu_baseline"] = cpu_baseline(host_in, args.kind)
         print(json.dumps(res), flush=True)
-    ctx.index_free(index)
+    wd.close()
+    for b in sets:
+        if b.index is not None:
+            ctx.index_free(b.index)
     for cm in comms or []:
         ctx.comm_destroy(cm)
     for cx in reversed(ctxs):

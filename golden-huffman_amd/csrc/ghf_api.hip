@@ -269,6 +269,13 @@ int ghf_copy_d2h(ghf_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
   if (bytes) GHF_HIP(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
   return GHF_OK;
 }
+int ghf_copy_d2d(ghf_ctx* c, void* d_dst, const void* d_src, size_t bytes, int non_temporal) {
+  if (!c || (bytes && (!d_dst || !d_src))) return GHF_E_INVAL;
+  if (!aligned16(d_dst) || !aligned16(d_src)) return fail(c, GHF_E_INVAL, "ghf_copy_d2d: 16-byte aligned pointers");
+  GHF_HIP(c, hipSetDevice(c->device));
+  if (bytes) launch_stream_copy(static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst), bytes, non_temporal != 0, c->stream);
+  return GHF_OK;
+}
 int ghf_memset_d(ghf_ctx* c, void* d_dst, int value, size_t bytes) {
   if (!c || (bytes && !d_dst)) return GHF_E_INVAL;
   GHF_HIP(c, hipSetDevice(c->device));

@@ -9,11 +9,15 @@
 //     loads ITS 16 contiguous symbols with one coalesced 16-byte load and looks the 16 codes up in a 32x replicated
 //     LDS table (replica = lane % 32: conflict-free for any data);
 //   * four neighbouring symbols are fused into one item of at most 64 bits (codes <= 16 bits; two symbols for longer
-//     codes), a DPP prefix sum of the items' lengths gives every lane its bit position, and each item is OR-ed into
-//     the wave's LDS bit string as three 32-bit words (ds_or_b32).  No per-lane serial accumulator, no data-dependent
-//     branch: the hot loop is straight-line code;
-//   * completed 16-byte units are copied out coalesced (and their LDS words cleared); the incomplete last unit is
-//     carried to the next tile;
+//     codes) and a DPP prefix sum of the items' lengths gives every lane its bit position in the wave's LDS bit string;
+//   * codes <= 16 bits (every BASELINE config): the lane's four items are concatenated IN REGISTERS into its whole run
+//     of <= 256 bits, shifted to the bit phase of its position, and stored with PLAIN ds_write_b32 -- every dword of the
+//     bit string is written exactly once by the first lane that touches it; only a lane's FIRST dword, which it may share
+//     with the lanes in front of it, is OR-ed in (one ds_or_b32 per lane and tile instead of twelve, nothing to clear
+//     afterwards: round 2's PMC had 49 % of this kernel's LDS cycles as bank-conflict cycles of those atomics).
+//     Longer codes (rare) keep the three ds_or_b32 per item;
+//   * no per-lane serial accumulator, no data-dependent branch: the hot loop is straight-line code;
+//   * completed 16-byte units are copied out coalesced; the incomplete last unit is carried to the next tile;
 //   * the 16-byte unit a chunk shares with its predecessor belongs to the LATER chunk: its wave re-encodes the last
 //     symbols of the previous chunk (or takes the header bytes) to fill the bits in front of its own first code, so
 //     every output byte is written exactly once, by one plain store.
@@ -96,27 +100,184 @@ __device__ __forceinline__ uint32_t emit_items(WaveOut& W, const uint64_t (&q)[N
   return total;
 }
 
+// ---- codes <= 16 bits: the lane's whole run leaves as plain stores -------------------------------------------------
+// ML = the longest code the instantiation handles (9, 12 or 16).  A lane's four items (right-justified, <= 4 * ML bits
+// each) become ONE left-justified string S of T <= 16 * ML bits:
+//   V_k = item k left-justified in 64 bits;  P0 = V0 ++ V1,  P1 = V2 ++ V3  (two 64-bit shifts each);
+//   S   = P0 | P1 >> (l0 + l1): a bit shift (v_alignbit) and a placement by 0..4 whole dwords (a two- or three-stage
+//         select network -- registers cannot be indexed);
+//   r[] = S >> (p & 31): the NW = ceil(16 ML / 32) + 1 dwords of the staging area the run touches, from dword p >> 5 on.
+// Ownership: dword d of the bit string belongs to the FIRST lane that touches it.  That lane stores it whole (its own bits,
+// zeros behind them); every later lane that begins inside d ORs its first dword in afterwards (LDS executes a wave's
+// instructions in order).  So: r[1..nw-1] are plain stores, r[0] is a plain store when the run begins on a dword
+// boundary and a ds_or_b32 otherwise.  The tile's very first dword holds the carry of the previous tile (or the bits
+// in front of the chunk), stored the same way.  Nothing is cleared: a dword is complete before it is copied out, and
+// what lies behind the last run is overwritten by its first toucher in the next tile.  Lanes with no bits (ragged last
+// tile, the end-mark pass) store nothing; any number of lanes may share a dword.
+template <int ML>
+struct WinGeom {
+  static constexpr int NP = (8 * ML + 31) / 32;   // dwords of a half (two items): 3, 3, 4
+  static constexpr int NS = (16 * ML + 31) / 32;  // dwords of the run: 5, 6, 8
+  static constexpr int NW = NS + 1;               // dwords of the staging area it can touch (31 + 16 ML bits): 6, 7, 9
+};
+
+// X (lx valid bits, left-justified) followed by Y (left-justified): the first 128 bits of the concatenation.
+// lx == 0 implies Y == 0 here (the valid symbols of a lane are a prefix of its sixteen).
+template <int ML>
+__device__ __forceinline__ void cat_left64(uint64_t X, uint32_t lx, uint64_t Y, uint32_t (&P)[WinGeom<ML>::NP]) {
+  uint64_t ys = Y >> (lx & 63u);
+  if (ML > 15) ys = (lx == 64u) ? 0ull : ys;  // (a shift by 64 is a shift by 0 to the hardware)
+  const uint64_t hi = X | ys;
+  const uint64_t lo = Y << ((64u - lx) & 63u);
+  P[0] = (uint32_t)(hi >> 32);
+  P[1] = (uint32_t)hi;
+  P[2] = (uint32_t)(lo >> 32);
+  if (WinGeom<ML>::NP > 3) P[WinGeom<ML>::NP - 1] = (uint32_t)lo;
+}
+
+// KIND 0: any tile (ragged, the end-mark pass; lanes may be empty), every store under its own condition.
+// KIND 1 / 2: a full tile of the main loop, with / without side-car.  All global stores are then UNCONDITIONAL straight-line
+// instructions (a lane with nothing to store repeats its neighbour's store: same address, same value), so that the
+// compiler can count them: gfx9 has ONE in-order counter for loads and stores, and the wait for a tile that was
+// requested four tiles ago is "all but the youngest 3 loads + 4 x stores-per-tile" only if that number is known.
+template <int ML, int KIND>
+__device__ __forceinline__ uint32_t emit_window(WaveOut& W, const uint64_t (&q)[4], const uint32_t (&l)[4], int lane,
+                                                uint32_t* seg_dst, uint32_t seg_base, uint64_t* blk_dst, uint64_t blk_val) {
+  constexpr int NP = WinGeom<ML>::NP, NS = WinGeom<ML>::NS, NW = WinGeom<ML>::NW;
+  const uint32_t L0 = l[0] + l[1];
+  const uint32_t T = L0 + l[2] + l[3];
+  const uint32_t incl = wave_incl_scan_u32(T);
+  const uint32_t total = wave_last_u32(incl);
+  const uint32_t p = W.carry + (incl - T);  // my first bit, relative to st[0]
+  // ---- the run, left-justified
+  uint32_t P0[NP], P1[NP];
+  cat_left64<ML>(q[0] << ((64u - l[0]) & 63u), l[0], q[1] << ((64u - l[1]) & 63u), P0);
+  cat_left64<ML>(q[2] << ((64u - l[2]) & 63u), l[2], q[3] << ((64u - l[3]) & 63u), P1);
+  uint32_t S[NS];
+  {
+    const uint32_t bs = L0 & 31u, ws = L0 >> 5;  // ws <= 8 ML / 32; the top value only with bs == 0
+    uint32_t t[NP + 1];
+    t[0] = P1[0] >> bs;
+#pragma unroll
+    for (int i = 1; i < NP; ++i) t[i] = alignbit(P1[i - 1], P1[i], bs);
+    t[NP] = alignbit(P1[NP - 1], 0u, bs);
+    const bool b0 = (ws & 1u) != 0, b1 = (ws & 2u) != 0;
+    uint32_t u[NS], v[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const uint32_t a = k <= NP ? t[k <= NP ? k : 0] : 0u;
+      const uint32_t b = (k >= 1 && k - 1 <= NP) ? t[(k >= 1 && k - 1 <= NP) ? k - 1 : 0] : 0u;
+      u[k] = b0 ? b : a;
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) v[k] = b1 ? (k >= 2 ? u[k >= 2 ? k - 2 : 0] : 0u) : u[k];
+    if (ML > 12) {  // ws == 4: both halves are full (L0 == 128)
+      const bool b2 = (ws & 4u) != 0;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) u[k] = b2 ? (k >= 4 ? v[k >= 4 ? k - 4 : 0] : 0u) : v[k];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) v[k] = u[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) S[k] = (k < NP ? P0[k < NP ? k : 0] : 0u) | v[k];
+  }
+  // ---- ... at its bit phase
+  const uint32_t sh = p & 31u;
+  uint32_t r[NW];
+  r[0] = S[0] >> sh;
+#pragma unroll
+  for (int k = 1; k < NS; ++k) r[k] = alignbit(S[k - 1], S[k], sh);
+  r[NS] = alignbit(S[NS - 1], 0u, sh);
+  const uint32_t nw = (sh + T + 31u) >> 5;  // dwords touched (0: no bits and on a boundary)
+  uint32_t* const w = W.st + (p >> 5);
+#pragma unroll
+  for (int k = 1; k < NW; ++k)
+    if ((uint32_t)k < nw) w[k] = r[k];
+  if (sh == 0u && T != 0u) w[0] = r[0];
+  wave_sync();
+  if (sh != 0u) atomicOr(w, r[0]);  // T == 0: ORs nothing
+  wave_sync();
+  const uint32_t endbits = W.carry + total;
+  const uint32_t U = endbits >> 7;  // <= 128
+  if constexpr (KIND == 0) {
+    if (seg_dst) *seg_dst = seg_base + incl;  // side-car: where this lane's segment ends, relative to its block
+    if (blk_dst) *blk_dst = blk_val;          // side-car: where the block begins (one lane, every fourth tile)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t j = (uint32_t)lane + 64u * h;
+      if (j < U) {
+        uint4 v = reinterpret_cast<const uint4*>(W.st)[j];
+        v.x = bswap32(v.x); v.y = bswap32(v.y); v.z = bswap32(v.z); v.w = bswap32(v.w);
+        W.out_units[W.unit_base + j] = v;
+      }
+    }
+  } else {
+    if constexpr (KIND == 1) {
+      // the segment's end is the inclusive sum of its fourth lane: all four lanes store it (quad_perm [3,3,3,3])
+      const uint32_t seg_end = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0xFF, 0xF, 0xF, false);
+      *seg_dst = seg_base + seg_end;
+      if (blk_dst) *blk_dst = blk_val;  // (compile-time: the first tile of a block; every lane, one address)
+    }
+    // a full tile holds >= 1024 bits: U >= 8; lanes behind the last complete unit repeat it
+    constexpr int NH = ML > 8 ? 2 : 1;  // <= 8-bit codes: at most 127 + 8192 bits, 64 units
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      uint32_t j = (uint32_t)lane + 64u * h;
+      j = j < U ? j : U - 1u;
+      uint4 v = reinterpret_cast<const uint4*>(W.st)[j];
+      v.x = bswap32(v.x); v.y = bswap32(v.y); v.z = bswap32(v.z); v.w = bswap32(v.w);
+      W.out_units[W.unit_base + j] = v;
+    }
+  }
+  wave_sync();
+  if (KIND != 0 || U) {  // the incomplete unit moves to the front (its partial dword: bits, then zeros; behind it: don't care)
+    if (lane < 4) {
+      const uint32_t t = W.st[4 * U + lane];
+      W.st[lane] = t;
+    }
+    W.unit_base += U;
+    wave_sync();
+  }
+  W.carry = endbits & 127u;
+  return total;
+}
+
 // ---- table entries ----
-// codes <= 16 bits: u32 = len << 16 | code, 32 replicas; a lane's four-symbol item comes from one input dword
-__device__ __forceinline__ void items_narrow(const uint32_t* tab, uint32_t r, const uint4& v, uint32_t cnt, uint64_t (&q)[4],
-                                             uint32_t (&l)[4]) {
+// codes <= 16 bits: u32 = len << 16 | code, 32 replicas; a lane's four-symbol item comes from one input dword.
+// Two steps, so that the main loop can re-load the tile register between them: once the sixteen table addresses are
+// formed the input bytes are dead, and the next tile can land in the SAME registers (a reload issued while the old
+// bytes are still needed costs a second register set and, at the loop's back edge, copies behind a full vmcnt(0)).
+__device__ __forceinline__ void lookup_narrow(const uint32_t* tab, uint32_t r, const uint4& v, uint32_t (&e)[16]) {
   const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    uint32_t e[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t b = (vv[k] >> (8 * j)) & 0xFFu;
-      e[j] = tab[(b << 5) | r];
-      if ((uint32_t)(4 * k + j) >= cnt) e[j] = 0;  // folds away for cnt == 16
+      e[4 * k + j] = tab[(b << 5) | r];
     }
-    const uint32_t l1 = e[1] >> 16, l3 = e[3] >> 16;
-    const uint32_t p0 = ((e[0] & 0xFFFFu) << l1) | (e[1] & 0xFFFFu);
-    const uint32_t p1 = ((e[2] & 0xFFFFu) << l3) | (e[3] & 0xFFFFu);
-    const uint32_t lp1 = (e[2] >> 16) + l3;
-    q[k] = ((uint64_t)p0 << lp1) | p1;
-    l[k] = (e[0] >> 16) + l1 + lp1;
   }
+}
+__device__ __forceinline__ void combine_narrow(uint32_t (&e)[16], uint32_t cnt, uint64_t (&q)[4], uint32_t (&l)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((uint32_t)(4 * k + j) >= cnt) e[4 * k + j] = 0;  // folds away for cnt == 16
+    const uint32_t* ek = e + 4 * k;
+    const uint32_t l1 = ek[1] >> 16, l3 = ek[3] >> 16;
+    const uint32_t p0 = ((ek[0] & 0xFFFFu) << l1) | (ek[1] & 0xFFFFu);
+    const uint32_t p1 = ((ek[2] & 0xFFFFu) << l3) | (ek[3] & 0xFFFFu);
+    const uint32_t lp1 = (ek[2] >> 16) + l3;
+    q[k] = ((uint64_t)p0 << lp1) | p1;
+    l[k] = (ek[0] >> 16) + l1 + lp1;
+  }
+}
+__device__ __forceinline__ void items_narrow(const uint32_t* tab, uint32_t r, const uint4& v, uint32_t cnt, uint64_t (&q)[4],
+                                             uint32_t (&l)[4]) {
+  uint32_t e[16];
+  lookup_narrow(tab, r, v, e);
+  combine_narrow(e, cnt, q, l);
 }
 
 // codes up to 32 bits: u64 = len << 32 | code, 16 replicas; two symbols per item
@@ -135,11 +296,12 @@ __device__ __forceinline__ void items_wide(const uint64_t* tab, uint32_t r, cons
   }
 }
 
-template <bool WIDE>
-struct EmitMode;
-template <>
-struct EmitMode<false> {
+// MODE 0: codes up to 32 bits (u64 table entries, eight two-symbol items per lane, ds_or_b32 deposits);
+// MODE 1 / 2 / 3: codes up to 9 / 12 / 16 bits (u32 entries, four four-symbol items, the lane's run as plain stores)
+template <int MODE>
+struct EmitMode {
   static constexpr int NI = 4;
+  static constexpr int ML = MODE == 1 ? 9 : (MODE == 2 ? 12 : 16);
   static __device__ __forceinline__ void items(const uint32_t* tab, int lane, const uint4& v, uint32_t cnt, uint64_t (&q)[4],
                                                uint32_t (&l)[4]) {
     items_narrow(tab, (uint32_t)lane & 31u, v, cnt, q, l);
@@ -151,8 +313,9 @@ struct EmitMode<false> {
   }
 };
 template <>
-struct EmitMode<true> {
+struct EmitMode<0> {
   static constexpr int NI = 8;
+  static constexpr int ML = 32;
   static __device__ __forceinline__ void items(const uint32_t* tab, int lane, const uint4& v, uint32_t cnt, uint64_t (&q)[8],
                                                uint32_t (&l)[8]) {
     items_wide(reinterpret_cast<const uint64_t*>(tab), (uint32_t)lane & 15u, v, cnt, q, l);
@@ -166,15 +329,17 @@ struct EmitMode<true> {
 
 // A tile's items -> output.  Codes <= 16 bits: one pass (<= 127 + 1024 * 16 bits fit the staging area).  Longer codes:
 // the two half-waves one after the other, each at most 32 lanes x 512 bits.
-template <bool WIDE, bool DRAIN>
-__device__ __forceinline__ uint32_t emit_tile(WaveOut& W, const uint64_t (&q)[EmitMode<WIDE>::NI],
-                                              const uint32_t (&l)[EmitMode<WIDE>::NI], int lane, uint32_t* seg_out,
+template <int MODE, int KIND>
+__device__ __forceinline__ uint32_t emit_tile(WaveOut& W, const uint64_t (&q)[EmitMode<MODE>::NI],
+                                              const uint32_t (&l)[EmitMode<MODE>::NI], int lane, uint32_t* seg_out,
                                               bool seg_valid, uint32_t relbits, uint64_t* blk_dst, uint64_t blk_val) {
-  constexpr int NI = EmitMode<WIDE>::NI;
-  uint32_t* const seg_dst = (seg_out && seg_valid && (lane & 3) == 3) ? seg_out : nullptr;  // stored with the tile's units
-  if (!WIDE) {
-    return emit_items<NI, DRAIN>(W, q, l, true, lane, seg_dst, relbits, blk_dst, blk_val);
+  constexpr int NI = EmitMode<MODE>::NI;
+  if constexpr (MODE != 0) {
+    uint32_t* seg_dst = seg_out;
+    if (KIND == 0) seg_dst = (seg_out && seg_valid && (lane & 3) == 3) ? seg_out : nullptr;  // stored with the tile's units
+    return emit_window<EmitMode<MODE>::ML, KIND>(W, q, l, lane, seg_dst, relbits, blk_dst, blk_val);
   } else {
+    uint32_t* const seg_dst = (seg_out && seg_valid && (lane & 3) == 3) ? seg_out : nullptr;
     uint32_t total = 0;
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
@@ -191,10 +356,11 @@ struct EmitGeom {      // wave-uniform facts about the stream
   int max_len;
 };
 
-template <bool WIDE>
+template <int MODE>
 __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& G, uint32_t c, const uint32_t* tab,
                                            uint32_t* flat, uint32_t* st, int lane) {
-  typedef EmitMode<WIDE> M;
+  typedef EmitMode<MODE> M;
+  constexpr bool WIDE = MODE == 0;
   constexpr int NI = M::NI;
   const uint64_t chunk = P.chunk;
   const uint64_t sym0 = (uint64_t)c * chunk;
@@ -214,12 +380,16 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
   }
   const uint64_t nfull = aligned ? (nsym / kSymPerIter) : 0;
   const uint4* pv = reinterpret_cast<const uint4*>(pin) + lane;
-  const bool streamed = !WIDE && nfull >= 2;  // (codes beyond 16 bits take the plain loop below: rare, and it keeps that
-                                              // instantiation free of spills)
-  uint4 A = make_uint4(0, 0, 0, 0), B = A;
+  // codes beyond 16 bits take the plain loop below (rare, and it keeps that instantiation free of spills); a side-car is
+  // written whole or not at all
+  constexpr int NB = 4;  // tile buffers = tiles per trip of the main loop = one side-car block
+  const bool streamed = !WIDE && nfull >= (uint64_t)NB && ((P.seg_bit != nullptr) == (P.chunk_bit != nullptr));
+  uint4 buf[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) buf[j] = make_uint4(0, 0, 0, 0);
   if (streamed) {
-    A = pv[0];
-    B = pv[64];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) buf[j] = pv[j * 64];
   }
   const uint64_t Pc = G.start_bit + chunk_off;
   WaveOut W;
@@ -289,31 +459,39 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
   };
   uint32_t* const segp = P.seg_bit ? P.seg_bit + ((sym0 + (uint64_t)lane * 16) >> 6) : nullptr;
   uint64_t it = 0;
-  // ---- full 1 KiB tiles, two per trip.  While tile `it` is packed, the loads of tiles it+1 and it+2 are in flight;
-  //      A and B are each re-loaded right after they were consumed, so no register ever has to be copied while
-  //      its load is pending (the last prefetches are clamped to the last full tile and simply unused).
-  if (streamed) {
-    __builtin_amdgcn_s_waitcnt(0x0F71);  // vmcnt(1): A has arrived, so the loop is entered in the state its back edge leaves
-    for (; it + 1 < nfull; it += 2) {
-      {
-        const uint4 v = A;
-        const uint64_t nx = (it + 2 < nfull) ? it + 2 : nfull - 1;
-        A = pv[nx * 64];
-        uint64_t q[NI];
-        uint32_t l[NI];
-        M::items(tab, lane, v, 16, q, l);
-        tile_done(it, emit_tile<WIDE, !WIDE>(W, q, l, lane, segp ? segp + it * 16 : nullptr, true, blockrel, block_dst(it),
-                                             bit_origin + relbits));
-      }
-      {
-        const uint4 v = B;
-        const uint64_t nx = (it + 3 < nfull) ? it + 3 : nfull - 1;
-        B = pv[nx * 64];
-        uint64_t q[NI];
-        uint32_t l[NI];
-        M::items(tab, lane, v, 16, q, l);
-        tile_done(it + 1, emit_tile<WIDE, !WIDE>(W, q, l, lane, segp ? segp + (it + 1) * 16 : nullptr, true, blockrel, nullptr, 0));
-      }
+  // ---- full 1 KiB tiles, four per trip (= one side-car block).  While a tile is packed the loads of the next THREE are in
+  //      flight: a buffer is re-loaded as soon as its bytes have become table addresses (same registers, no copy), and every
+  //      global store of the trip is an unconditional straight-line instruction, so the compiler's own wait in front of a
+  //      buffer's first use is "all but the 3 younger loads and the stores issued since" -- the in-order vmcnt of gfx9
+  //      would otherwise force every prefetch to land before the NEXT tile's stores.  The loop is entered with nothing in
+  //      flight (one full wait per chunk), so that these waits are computed from its own back edge alone.  The last
+  //      prefetches are clamped to the last full tile and simply unused.
+  if constexpr (!WIDE) {
+    if (streamed) {
+      auto trips = [&](auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        for (; it + NB <= nfull; it += NB) {
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            uint32_t e[16];
+            lookup_narrow(tab, (uint32_t)lane & 31u, buf[j], e);
+            __builtin_amdgcn_sched_barrier(0);  // the bytes of buf[j] are consumed: its registers take the next load
+            const uint64_t nx = (it + NB + j < nfull) ? it + NB + j : nfull - 1;
+            buf[j] = pv[nx * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            uint64_t q[NI];
+            uint32_t l[NI];
+            combine_narrow(e, 16, q, l);
+            const uint32_t total = emit_tile<MODE, KIND>(W, q, l, lane, KIND == 1 ? segp + (it + j) * 16 : nullptr, true, blockrel,
+                                                         (KIND == 1 && j == 0) ? blockp + (it >> 2) : nullptr, bit_origin + relbits);
+            relbits += total;
+            blockrel = (j == NB - 1) ? 0u : blockrel + total;
+          }
+        }
+      };
+      if (segp) trips(std::integral_constant<int, 1>{});
+      else trips(std::integral_constant<int, 2>{});
     }
   }
   // ---- whatever is left: an odd full tile, the ragged tail, unaligned input, and -- on the stream's last chunk --
@@ -359,13 +537,19 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
         l[0] = el + pad;
       }
     }
-    tile_done(it, emit_tile<WIDE, false>(W, q, l, lane, seg_out, seg_valid, blockrel, blk, bit_origin + relbits));
+    tile_done(it, emit_tile<MODE, 0>(W, q, l, lane, seg_out, seg_valid, blockrel, blk, bit_origin + relbits));
   }
   // the chunk's last, incomplete unit belongs to the next chunk's wave -- unless this is the buffer's last chunk
+  // (what lies behind the last bit is stored as zeros: a neighbouring shard or file piece ORs its own bits into this unit)
   if (c + 1 == P.nchunks && W.carry && lane == 0) {
-    uint4 v = *reinterpret_cast<const uint4*>(st);
-    v.x = bswap32(v.x); v.y = bswap32(v.y); v.z = bswap32(v.z); v.w = bswap32(v.w);
-    W.out_units[W.unit_base] = v;
+    const uint4 v = *reinterpret_cast<const uint4*>(st);
+    uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vb = (int)W.carry - 32 * i;  // valid bits of this dword
+      ww[i] = vb >= 32 ? ww[i] : (vb <= 0 ? 0u : (ww[i] & (~0u << (32 - vb))));
+    }
+    W.out_units[W.unit_base] = make_uint4(bswap32(ww[0]), bswap32(ww[1]), bswap32(ww[2]), bswap32(ww[3]));
   }
 }
 
@@ -403,6 +587,11 @@ __global__ __launch_bounds__(kEmitThreads, 6) void k_emit(EmitParams P) {
     // thread -> symbol tid / 2, replicas 16 * (tid & 1) ..  (u32) or 8 * (tid & 1) .. (u64): 64 bytes each
     const int s = tid >> 1;
     const uint32_t code = P.code->codeword[s], len = P.code->length[s];
+    // the tables may be the caller's own: the packers below size their registers and the staging area by max_len
+    if (__syncthreads_or(len > (uint32_t)G.max_len || G.max_len > 32 || G.max_len < 1)) {
+      if (tid == 0) latch_status(P.status, GHF_E_FORMAT);
+      return;
+    }
     uint4 v;
     if (!wide) {
       const uint32_t e = (len << 16) | (code & 0xFFFFu);
@@ -418,8 +607,11 @@ __global__ __launch_bounds__(kEmitThreads, 6) void k_emit(EmitParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell the compiler it is wave-uniform (SGPR)
   const uint32_t c = blockIdx.x * kEmitWaves + wave;
   if (c >= P.nchunks) return;
-  if (!wide) emit_chunk<false>(P, G, c, tab, stage, stage + wave * kStageWords, lane);
-  else emit_chunk<true>(P, G, c, tab, stage, stage + wave * kStageWords, lane);
+  uint32_t* const st = stage + wave * kStageWords;
+  if (G.max_len <= 9) emit_chunk<1>(P, G, c, tab, stage, st, lane);
+  else if (G.max_len <= 12) emit_chunk<2>(P, G, c, tab, stage, st, lane);
+  else if (!wide) emit_chunk<3>(P, G, c, tab, stage, st, lane);
+  else emit_chunk<0>(P, G, c, tab, stage, st, lane);
 }
 
 void launch_emit(const EmitParams& p, hipStream_t s) {

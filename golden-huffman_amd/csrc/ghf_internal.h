@@ -148,6 +148,7 @@ void launch_crs_build_code(const uint64_t* d_hist, ghf_tree* d_tree, ghf_code* d
 void launch_crs_finish(const ghf_tree* d_tree, const uint64_t* d_total_bits, uint8_t* d_out, uint64_t* d_out_bytes, int* d_status,
                        hipStream_t s);
 void launch_crs_decode_tables(const ghf_tree* d_tree, DecTables* d_dt, int* d_status, hipStream_t s);
+void launch_stream_copy(const uint8_t* d_src, uint8_t* d_dst, uint64_t n, bool nt, hipStream_t s);
 void launch_store_u64(uint64_t* d_dst, const uint64_t* d_src_opt, uint64_t add, hipStream_t s);
 void launch_shard_start(const ghf_code* d_code, const uint64_t* d_totals, int rank, uint64_t* d_start_bit, hipStream_t s);
 

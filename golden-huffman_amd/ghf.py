@@ -105,7 +105,7 @@ EXPORTS = [
     "ghf_comm_unique_id", "ghf_comm_init_rank", "ghf_comm_destroy", "ghf_comm_world", "ghf_rccl_version",
     "ghf_comm_allreduce_hist", "ghf_comm_allgather_total", "ghf_encode_sharded", "ghf_shard_bound",
     "ghf_event_create", "ghf_event_destroy", "ghf_event_record", "ghf_event_wait", "ghf_event_sync", "ghf_histogram_add",
-    "ghf_crs_sync_piece",
+    "ghf_crs_sync_piece", "ghf_copy_d2d",
 ]
 COMM_ID_BYTES = 128
 
@@ -145,6 +145,7 @@ def lib():
     L.ghf_copy_h2d.argtypes = [vp, vp, vp, sz]
     L.ghf_copy_d2h.argtypes = [vp, vp, vp, sz]
     L.ghf_memset_d.argtypes = [vp, vp, i32, sz]
+    L.ghf_copy_d2d.argtypes = [vp, vp, vp, sz, i32]
     L.ghf_histogram.argtypes = [vp, vp, sz, vp]
     L.ghf_histogram_add.argtypes = [vp, vp, sz, vp]
     L.ghf_event_create.argtypes = [vp, C.POINTER(vp)]
@@ -325,6 +326,11 @@ class Context:
 
         a = np.frombuffer(bytes(code), dtype=np.uint8).copy()
         return self.torch.from_numpy(a).to(self.device)
+
+    def copy_d2d(self, d_dst, d_src, n=None, non_temporal=True):
+        """the library's streaming copy kernel (bandwidth probe)"""
+        n = d_src.numel() if n is None else n
+        self._chk(self.L.ghf_copy_d2d(self.h, d_dst.data_ptr(), d_src.data_ptr(), n, 1 if non_temporal else 0), "ghf_copy_d2d")
 
     # ---- stages --------------------------------------------------------------------------------
     def histogram(self, d_in, n=None, out=None):

@@ -93,6 +93,12 @@ int ghf_host_free(ghf_ctx* ctx, void* h_ptr);
 int ghf_copy_h2d(ghf_ctx* ctx, void* d_dst, const void* h_src, size_t bytes); /* async on the stream */
 int ghf_copy_d2h(ghf_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* async on the stream */
 int ghf_memset_d(ghf_ctx* ctx, void* d_dst, int value, size_t bytes);
+/* Device-to-device copy by a kernel with this path's own access shape (16 bytes per lane, four loads in
+ * flight, one resident round of workgroups; non_temporal != 0: `global_load/store ... nt`, the hint K1 and K7
+ * stream with).  Both pointers 16-byte aligned.  No reference counterpart: it is the bandwidth probe bench.py
+ * prices the codec kernels against (what a kernel that only moves the bytes reaches on this box), async on
+ * the stream. */
+int ghf_copy_d2d(ghf_ctx* ctx, void* d_dst, const void* d_src, size_t bytes, int non_temporal);
 
 /* ---- events: ordering between the streams of several contexts without stopping the host ----------
  * (the file pipeline of golden-huffman_amd/host/glzip_hip.h, which replaces the reference's 64 KiB

@@ -184,21 +184,43 @@ def test_encode_sharded_c_abi_world1_over_rccl():
         ctx.close()
 
 
-def test_bench_two_rank_rehearsal():
-    """bench.py's N>1 control flow (offsets, flags, pipelining, index flags, round-trip check) with two ranks on
-    this one GPU: `--backend gloo` stages the two collectives through the host.  The RCCL run is the driver's."""
-    import json
+def _bench_two_ranks(extra_env=None, timeout=400):
     import subprocess
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29900 + os.getpid() % 90), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
            "--backend", "gloo", "--mib", "32"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's N>1 control flow (offsets, flags, pipelining over rotating buffer sets, index flags, round-trip checks, the
+    same-shard single-GPU run in front of the sharded one) with two ranks on this one GPU: `--backend gloo` stages the
+    two collectives through the host.  The RCCL run is the driver's."""
+    import json
+
+    r = _bench_two_ranks()
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["config"]["parallelism"] == "shard2"
+    assert d["config"]["parallelism"] == "shard2" and d["config"]["buffer_sets"] >= 3
+    assert d["config"]["side_streams"] == 1  # N > 1: collectives in strict step order on one stream
+    assert d["same_shard_1gpu_ms_per_step"] > 0 and d["speedup_vs_same_shard"] > 0
+
+
+def test_bench_watchdog_names_the_stuck_stage():
+    """a rank that never joins a collective must end the run within the step timeout, with the stage named -- not sit there
+    until the driver's limit (rank 1 stays away from step 1's all-reduce)."""
+    import time
+
+    t0 = time.time()
+    r = _bench_two_ranks({"GHF_BENCH_INJECT_HANG": "1:1", "GHF_BENCH_STEP_TIMEOUT": "8"}, timeout=300)
+    assert r.returncode != 0
+    assert "no progress for 8 s" in r.stderr and "allreduce of step 1" in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 200
 
 
 def _foreign_worker(rank, world, port, kind, n_total, q):
