@@ -102,23 +102,21 @@ __device__ __forceinline__ uint32_t emit_items(WaveOut& W, const uint64_t (&q)[N
 
 // ---- codes <= 16 bits: the lane's whole run leaves as plain stores -------------------------------------------------
 // ML = the longest code the instantiation handles (9, 12 or 16).  A lane's four items (right-justified, <= 4 * ML bits
-// each) become ONE left-justified string S of T <= 16 * ML bits:
+// each) become TWO left-justified strings of <= 8 * ML bits, its HALVES (eight symbols each):
 //   V_k = item k left-justified in 64 bits;  P0 = V0 ++ V1,  P1 = V2 ++ V3  (two 64-bit shifts each);
-//   S   = P0 | P1 >> (l0 + l1): a bit shift (v_alignbit) and a placement by 0..4 whole dwords (a two- or three-stage
-//         select network -- registers cannot be indexed);
-//   r[] = S >> (p & 31): the NW = ceil(16 ML / 32) + 1 dwords of the staging area the run touches, from dword p >> 5 on.
-// Ownership: dword d of the bit string belongs to the FIRST lane that touches it.  That lane stores it whole (its own bits,
-// zeros behind them); every later lane that begins inside d ORs its first dword in afterwards (LDS executes a wave's
-// instructions in order).  So: r[1..nw-1] are plain stores, r[0] is a plain store when the run begins on a dword
+//   rr[h][] = P_h >> (p_h & 31): the NP + 1 dwords of the staging area the half touches, from dword p_h >> 5 on
+// (concatenating the halves in registers as well costs a select network -- registers cannot be indexed -- of 40 VALU
+// instructions per lane and tile for two LDS stores less: measured, VALU is what this kernel is short of).
+// Ownership: dword d of the bit string belongs to the FIRST half that touches it.  That half stores it whole (its own bits,
+// zeros behind them); every later half that begins inside d ORs its first dword in afterwards (LDS executes a wave's
+// instructions in order).  So: rr[1..nw-1] are plain stores, rr[0] is a plain store when the half begins on a dword
 // boundary and a ds_or_b32 otherwise.  The tile's very first dword holds the carry of the previous tile (or the bits
 // in front of the chunk), stored the same way.  Nothing is cleared: a dword is complete before it is copied out, and
-// what lies behind the last run is overwritten by its first toucher in the next tile.  Lanes with no bits (ragged last
-// tile, the end-mark pass) store nothing; any number of lanes may share a dword.
+// what lies behind the last half is overwritten by its first toucher in the next tile.  Halves with no bits (ragged last
+// tile, the end-mark pass) store nothing; any number of halves may share a dword.
 template <int ML>
 struct WinGeom {
   static constexpr int NP = (8 * ML + 31) / 32;   // dwords of a half (two items): 3, 3, 4
-  static constexpr int NS = (16 * ML + 31) / 32;  // dwords of the run: 5, 6, 8
-  static constexpr int NW = NS + 1;               // dwords of the staging area it can touch (31 + 16 ML bits): 6, 7, 9
 };
 
 // X (lx valid bits, left-justified) followed by Y (left-justified): the first 128 bits of the concatenation.
@@ -143,7 +141,7 @@ __device__ __forceinline__ void cat_left64(uint64_t X, uint32_t lx, uint64_t Y, 
 template <int ML, int KIND>
 __device__ __forceinline__ uint32_t emit_window(WaveOut& W, const uint64_t (&q)[4], const uint32_t (&l)[4], int lane,
                                                 uint32_t* seg_dst, uint32_t seg_base, uint64_t* blk_dst, uint64_t blk_val) {
-  constexpr int NP = WinGeom<ML>::NP, NS = WinGeom<ML>::NS, NW = WinGeom<ML>::NW;
+  constexpr int NP = WinGeom<ML>::NP;
   const uint32_t L0 = l[0] + l[1];
   const uint32_t T = L0 + l[2] + l[3];
   const uint32_t incl = wave_incl_scan_u32(T);
@@ -153,49 +151,33 @@ __device__ __forceinline__ uint32_t emit_window(WaveOut& W, const uint64_t (&q)[
   uint32_t P0[NP], P1[NP];
   cat_left64<ML>(q[0] << ((64u - l[0]) & 63u), l[0], q[1] << ((64u - l[1]) & 63u), P0);
   cat_left64<ML>(q[2] << ((64u - l[2]) & 63u), l[2], q[3] << ((64u - l[3]) & 63u), P1);
-  uint32_t S[NS];
-  {
-    const uint32_t bs = L0 & 31u, ws = L0 >> 5;  // ws <= 8 ML / 32; the top value only with bs == 0
-    uint32_t t[NP + 1];
-    t[0] = P1[0] >> bs;
+  // ---- ... each half at its bit phase, NP + 1 dwords of the staging area from its first dword on
+  const uint32_t ph[2] = {p, p + L0};
+  const uint32_t lh[2] = {L0, T - L0};
+  uint32_t rr[2][NP + 1], sh[2];
+  uint32_t* w[2];
 #pragma unroll
-    for (int i = 1; i < NP; ++i) t[i] = alignbit(P1[i - 1], P1[i], bs);
-    t[NP] = alignbit(P1[NP - 1], 0u, bs);
-    const bool b0 = (ws & 1u) != 0, b1 = (ws & 2u) != 0;
-    uint32_t u[NS], v[NS];
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t(&Ph)[NP] = h ? P1 : P0;
+    sh[h] = ph[h] & 31u;
+    rr[h][0] = Ph[0] >> sh[h];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      const uint32_t a = k <= NP ? t[k <= NP ? k : 0] : 0u;
-      const uint32_t b = (k >= 1 && k - 1 <= NP) ? t[(k >= 1 && k - 1 <= NP) ? k - 1 : 0] : 0u;
-      u[k] = b0 ? b : a;
-    }
-#pragma unroll
-    for (int k = 0; k < NS; ++k) v[k] = b1 ? (k >= 2 ? u[k >= 2 ? k - 2 : 0] : 0u) : u[k];
-    if (ML > 12) {  // ws == 4: both halves are full (L0 == 128)
-      const bool b2 = (ws & 4u) != 0;
-#pragma unroll
-      for (int k = 0; k < NS; ++k) u[k] = b2 ? (k >= 4 ? v[k >= 4 ? k - 4 : 0] : 0u) : v[k];
-#pragma unroll
-      for (int k = 0; k < NS; ++k) v[k] = u[k];
-    }
-#pragma unroll
-    for (int k = 0; k < NS; ++k) S[k] = (k < NP ? P0[k < NP ? k : 0] : 0u) | v[k];
+    for (int k = 1; k < NP; ++k) rr[h][k] = alignbit(Ph[k - 1], Ph[k], sh[h]);
+    rr[h][NP] = alignbit(Ph[NP - 1], 0u, sh[h]);
+    w[h] = W.st + (ph[h] >> 5);
   }
-  // ---- ... at its bit phase
-  const uint32_t sh = p & 31u;
-  uint32_t r[NW];
-  r[0] = S[0] >> sh;
 #pragma unroll
-  for (int k = 1; k < NS; ++k) r[k] = alignbit(S[k - 1], S[k], sh);
-  r[NS] = alignbit(S[NS - 1], 0u, sh);
-  const uint32_t nw = (sh + T + 31u) >> 5;  // dwords touched (0: no bits and on a boundary)
-  uint32_t* const w = W.st + (p >> 5);
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t nw = (sh[h] + lh[h] + 31u) >> 5;  // dwords touched (0: no bits and on a boundary)
 #pragma unroll
-  for (int k = 1; k < NW; ++k)
-    if ((uint32_t)k < nw) w[k] = r[k];
-  if (sh == 0u && T != 0u) w[0] = r[0];
+    for (int k = 1; k <= NP; ++k)
+      if ((uint32_t)k < nw) w[h][k] = rr[h][k];
+    if (sh[h] == 0u && lh[h] != 0u) w[h][0] = rr[h][0];
+  }
   wave_sync();
-  if (sh != 0u) atomicOr(w, r[0]);  // T == 0: ORs nothing
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (sh[h] != 0u) atomicOr(w[h], rr[h][0]);  // (no bits: ORs nothing)
   wave_sync();
   const uint32_t endbits = W.carry + total;
   const uint32_t U = endbits >> 7;  // <= 128
@@ -584,23 +566,27 @@ __global__ __launch_bounds__(kEmitThreads, 6) void k_emit(EmitParams P) {
   if (!fits) return;
   const bool wide = G.max_len > 16;
   {
-    // thread -> symbol tid / 2, replicas 16 * (tid & 1) ..  (u32) or 8 * (tid & 1) .. (u64): 64 bytes each
-    const int s = tid >> 1;
-    const uint32_t code = P.code->codeword[s], len = P.code->length[s];
-    // the tables may be the caller's own: the packers below size their registers and the staging area by max_len
-    if (__syncthreads_or(len > (uint32_t)G.max_len || G.max_len > 32 || G.max_len < 1)) {
+    // 4 slots per symbol, each 32 bytes of the symbol's 128-byte row: replicas 8 * (i & 3) .. (u32) or 4 * (i & 3) .. (u64).
+    // The tables may be the caller's own: the packers below size their registers and the staging area by max_len.
+    bool bad = G.max_len > 32 || G.max_len < 1;
+    for (int i = tid; i < 1024; i += kEmitThreads) {
+      const int s = i >> 2;
+      const uint32_t code = P.code->codeword[s], len = P.code->length[s];
+      bad |= len > (uint32_t)G.max_len;
+      uint4 v;
+      if (!wide) {
+        const uint32_t e = (len << 16) | (code & 0xFFFFu);
+        v = make_uint4(e, e, e, e);
+      } else {
+        v = make_uint4(code, len, code, len);
+      }
+      uint4* dst = reinterpret_cast<uint4*>(tab) + (s * 8 + (i & 3) * 2);
+      dst[0] = v; dst[1] = v;
+    }
+    if (__syncthreads_or(bad)) {
       if (tid == 0) latch_status(P.status, GHF_E_FORMAT);
       return;
     }
-    uint4 v;
-    if (!wide) {
-      const uint32_t e = (len << 16) | (code & 0xFFFFu);
-      v = make_uint4(e, e, e, e);
-    } else {
-      v = make_uint4(code, len, code, len);
-    }
-    uint4* dst = reinterpret_cast<uint4*>(tab) + (s * 8 + (tid & 1) * 4);
-    dst[0] = v; dst[1] = v; dst[2] = v; dst[3] = v;
   }
   __syncthreads();
   const int lane = tid & 63;

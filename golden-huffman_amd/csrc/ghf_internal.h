@@ -16,7 +16,9 @@ constexpr int kBlockSymbols = 4096;     // side-car block = 64 segments = one K7
 // A chunk = the input one K5 wave packs (and the unit K1 prices for K4).  Chunks are sized so that ALL of them are resident
 // at once: K5 keeps 3 workgroups x 8 waves on each of the 256 CUs, and a grid of 1.33 rounds (8192 power-of-two chunks, as in
 // round 1) spends its last third with a third of the waves -- too few loads in flight to keep HBM busy.  Multiples of
-// 16 KiB (four rounds of K1's 4 KiB vector rows), at most 1 MiB.
+// 16 KiB (four rounds of K1's 4 KiB vector rows), at most 1 MiB.  (Round 3 tried 2 workgroups x 16 waves, 8 waves per SIMD:
+// 3 % faster alone, 12 % slower between the other kernels of the pipelined bench -- a 1024-thread workgroup needs half a
+// CU to drain before it can start.)
 constexpr uint32_t kChunkQuantum = 16384;
 constexpr uint32_t kMaxChunk = 1u << 20;
 constexpr uint32_t kEmitSlots = 256 * 3 * 8;

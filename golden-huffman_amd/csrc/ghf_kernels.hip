@@ -288,11 +288,15 @@ __device__ __forceinline__ u64t wave_heap_pop(HeapLds& h, int& n, int lane) {
   const int len = __builtin_amdgcn_readfirstlane(n) - 1;  // entries left behind (wave-uniform: keeps the walk on the scalar unit)
   n = len;
   const uint32_t tA = lane ? (uint32_t)lane : 128u, tB = 64u + (uint32_t)lane;
+  // (all four reads go out together and are waited for once: a pop is two LDS round trips, this one and the path's below)
   const U64x2 ca = *reinterpret_cast<const U64x2*>(&h.slot[2 * tA]);
   const U64x2 cb = *reinterpret_cast<const U64x2*>(&h.slot[2 * tB]);
-  const u64t top = wave_uniform(h.slot[1]);
+  const u64t top_v = h.slot[1];
+  const u64t value_v = h.slot[len + 1];  // (len == 0: slot[1] again, unused)
+  __builtin_amdgcn_sched_barrier(0);
+  const u64t top = wave_uniform(top_v);
   if (len < 1) return top;
-  const u64t value = wave_uniform(h.slot[len + 1]);  // the old last entry, re-inserted from the hole
+  const u64t value = wave_uniform(value_v);  // the old last entry, re-inserted from the hole
   // 1. "go right" = !comp(right, left) (libstdc++ takes the LEFT child when freq[right] > freq[left])
   const unsigned long long R0 = __ballot(!heap_gt(ca.y, ca.x));  // bit l = node l (l >= 1), bit 0 = node 128
   const unsigned long long R1 = __ballot(!heap_gt(cb.y, cb.x));  // bit l = node 64 + l
@@ -302,63 +306,70 @@ __device__ __forceinline__ u64t wave_heap_pop(HeapLds& h, int& n, int lane) {
   const int D = 31 - __clz(len);
   // seven levels unconditionally (two scalar instructions each), then cut the path back to its first D-1 steps: the
   // prefix of a longer walk IS the shorter walk (what lies below may be stale slots; it is shifted out)
+  // (t = 2 t + bit t of the map: s_bitcmp1_b64 puts the bit into SCC -- it looks at the low six bits of t only, which is
+  //  what level 7 wants -- and s_addc_u32 t, t, t adds it in: 14 scalar instructions for the 7 levels; the compiler's
+  //  shift / and / shift / or rendering of the same took 40)
   uint32_t t = 1;
-#pragma unroll
-  for (int d = 0; d < 6; ++d) t = 2u * t + (uint32_t)((R0 >> t) & 1ull);  // nodes 1..63
-  t = 2u * t + (uint32_t)((R1 >> (t & 63u)) & 1ull);                      // nodes 64..127
+  asm("s_bitcmp1_b64 %1, %0\n\ts_addc_u32 %0, %0, %0\n\t"
+      "s_bitcmp1_b64 %1, %0\n\ts_addc_u32 %0, %0, %0\n\t"
+      "s_bitcmp1_b64 %1, %0\n\ts_addc_u32 %0, %0, %0\n\t"
+      "s_bitcmp1_b64 %1, %0\n\ts_addc_u32 %0, %0, %0\n\t"
+      "s_bitcmp1_b64 %1, %0\n\ts_addc_u32 %0, %0, %0\n\t"
+      "s_bitcmp1_b64 %1, %0\n\ts_addc_u32 %0, %0, %0\n\t"  // nodes 1..63
+      "s_bitcmp1_b64 %2, %0\n\ts_addc_u32 %0, %0, %0"        // nodes 64..127
+      : "+s"(t)
+      : "s"(R0), "s"(R1)
+      : "scc");
   const int steps = D - 1 > 0 ? D - 1 : 0;
   t >>= 7 - steps;
   if (t <= lim) t = 2u * t + (uint32_t)(((t < 64u || t == 128u ? R0 : R1) >> (t & 63u)) & 1ull);  // depth D-1 where both children exist
   if ((len & 1) == 0 && t == (uint32_t)len >> 1) t = 2u * t;  // lone left child of an even-length heap
   const int k = 31 - __clz(t);  // depth of the hole
-  // 3. my nodes on the path?  node u at depth j < k is, iff t >> (k - j) == u; its path child is bit (k - j - 1) of t
-  auto on_path = [&](uint32_t u, const U64x2& c, u64t& cv, uint32_t& child) -> bool {
-    const int j = 31 - __clz(u);
-    const bool on = j < k && (t >> (k - j)) == u;
-    const uint32_t bit = on ? (t >> (k - j - 1)) & 1u : 0u;
-    cv = bit ? c.y : c.x;
-    child = 2u * u + bit;
-    return on;
-  };
-  u64t cvA, cvB;
-  uint32_t chA, chB;
-  const bool onA = on_path(tA, ca, cvA, chA), onB = on_path(tB, cb, cvB, chB);
-  // __push_heap from the hole: entries move back down while comp(entry, value); it stops at the deepest path entry with
-  // !comp.  Depth order = node order: node 128 (bit 0 of the A ballot) deepest, then nodes 64..127, then 63..1
-  const unsigned long long SA = __ballot(onA && !heap_gt(cvA, value));
-  const unsigned long long SB = __ballot(onB && !heap_gt(cvB, value));
-  int m = 0;  // depth of the entry that receives `value`
-  if (SA & 1ull) m = 8;
-  else if (SB) m = 7;
-  else if (SA >> 1) m = (31 - __clz((uint32_t)(63 - __clzll((long long)SA)))) + 1;
-  if (onA) {
-    const int j = 31 - __clz(tA);
-    if (j < m) h.slot[tA] = cvA;
-    if (j + 1 == m) h.slot[chA] = value;
-  }
-  if (onB) {  // depth 6
-    if (6 < m) h.slot[tB] = cvB;
-    if (7 == m) h.slot[chB] = value;
-  }
-  if (m == 0 && lane == 1) h.slot[1] = value;
+  // 3. lane j < k takes path node u_j = t >> (k - j): ONE more LDS read (the children pair of u_j) gives cv_j, the entry that
+  //    __adjust_heap moves up into u_j (its preferred child, which is path node u_{j+1}).  __push_heap from the hole then moves
+  //    entries back down while comp(entry, value); it stops below the DEEPEST path entry with !comp: with m = that depth + 1
+  //    (0: none), u_i receives cv_i for i < m, u_m receives `value`, everything deeper keeps what it had.
+  const uint32_t sh = (uint32_t)(k - lane) & 31u;
+  const bool onp = lane < k;
+  const uint32_t u = onp ? (t >> sh) : 1u;
+  const U64x2 c = *reinterpret_cast<const U64x2*>(&h.slot[2 * u]);
+  const u64t cv = ((t >> ((sh - 1u) & 31u)) & 1u) ? c.y : c.x;
+  const unsigned long long S = __ballot(onp && !heap_gt(cv, value));
+  const int m = S ? 64 - __clzll((long long)S) : 0;
+  if (lane <= m) h.slot[lane < m ? u : (t >> ((uint32_t)(k - m) & 31u))] = lane < m ? cv : value;
   wave_sync();  // the next heap operation reads, in OTHER lanes, what these lanes stored (without the fence the compiler may
                 // forward a lane's own store to its next load and let the other lanes' load overtake the store)
   return top;
 }
 
-// priority_queue::push(e) onto a heap of n entries: __push_heap from position n
-__device__ __forceinline__ void wave_heap_push(HeapLds& h, int n_, u64t e, int lane) {
+// priority_queue::push(e) onto a heap of n entries: __push_heap from position n.  In two steps, so that a caller can put
+// other LDS reads into the same round trip: lane j = 1..depth reads the j-th ancestor of the new position ...
+struct PushLoad {
+  u64t pe;
+  int aj, depth;
+  bool on;
+};
+__device__ __forceinline__ PushLoad wave_heap_push_load(const HeapLds& h, int n_, int lane) {
   const int n = __builtin_amdgcn_readfirstlane(n_);
-  const int depth = 31 - __clz(n + 1);  // number of ancestors of position n
-  const bool on = lane >= 1 && lane <= depth;
-  const int aj = ((n + 1) >> lane) - 1;  // lane 0: n itself
-  const u64t pe = on ? h.slot[aj + 1] : 0ull;
-  const bool stop = on && !heap_gt(pe, e);
+  PushLoad L;
+  L.depth = 31 - __clz(n + 1);  // number of ancestors of position n
+  L.on = lane >= 1 && lane <= L.depth;
+  L.aj = ((n + 1) >> lane) - 1;  // lane 0: n itself
+  L.pe = L.on ? h.slot[L.aj + 1] : 0ull;
+  return L;
+}
+// ... and the entries above the first ancestor that stays move down one level each (one ballot, one DPP shift)
+__device__ __forceinline__ void wave_heap_push_finish(HeapLds& h, const PushLoad& L, u64t e, int lane) {
+  const bool stop = L.on && !heap_gt(L.pe, e);
   const unsigned long long sm = __ballot(stop);
-  const int t = sm ? (__ffsll((long long)sm) - 1) - 1 : depth;  // entries of lanes 1..t move down one level
-  const u64t up = lane_above(pe);
-  if (lane <= t) h.slot[aj + 1] = (lane < t) ? up : e;
+  const int t = sm ? (__ffsll((long long)sm) - 1) - 1 : L.depth;  // entries of lanes 1..t move down one level
+  const u64t up = lane_above(L.pe);
+  if (lane <= t) h.slot[L.aj + 1] = (lane < t) ? up : e;
   wave_sync();
+}
+__device__ __forceinline__ void wave_heap_push(HeapLds& h, int n_, u64t e, int lane) {
+  const PushLoad L = wave_heap_push_load(h, n_, lane);
+  wave_heap_push_finish(h, L, e, lane);
 }
 
 struct CodeLds {  // the small per-length tables of K3; the per-symbol arrays go straight to global memory
@@ -500,13 +511,17 @@ __global__ __launch_bounds__(64) void k_build_code(const unsigned long long* __r
       const u64t e2 = wave_heap_pop(heap, n, lane);
       const int s1 = (int)(e1 & 511u), s2 = (int)(e2 & 511u);
       const int node = GHF_NSYM + t;
+      // one LDS round trip for the push's ancestors and the two groups' current tree nodes (every lane reads the same
+      // two words: no divergent block, no wait of its own)
+      const PushLoad pl = wave_heap_push_load(heap, n, lane);
+      const uint16_t g1 = heap.cur[s1], g2 = heap.cur[s2];
       if (lane == 0) {
-        heap.parent[heap.cur[s1]] = (uint16_t)node;  // .cc:316-329: both groups one level deeper ...
-        heap.parent[heap.cur[s2]] = (uint16_t)node;
-        heap.cur[s2] = (uint16_t)node;               // ... and merged under the second popped index
+        heap.parent[g1] = (uint16_t)node;  // .cc:316-329: both groups one level deeper ...
+        heap.parent[g2] = (uint16_t)node;
+        heap.cur[s2] = (uint16_t)node;     // ... and merged under the second popped index
       }
-      const u64t f = (e1 >> 9) + (e2 >> 9);                  // .cc:331
-      wave_heap_push(heap, n, (f << 9) | (u64t)s2, lane);    // .cc:333
+      const u64t f = (e1 >> 9) + (e2 >> 9);                              // .cc:331
+      wave_heap_push_finish(heap, pl, (f << 9) | (u64t)s2, lane);        // .cc:333
       ++n;
     }
   }
