@@ -298,6 +298,9 @@ def main():
     # never sit in front of K7's on a CU (256 MiB: decode stage 0.150 -> 0.141 ms).
     main = torch.cuda.Stream(priority=-1)
     torch.cuda.set_stream(main)
+    # GHF_BENCH_K1_STREAM=1: the histograms get a high-priority stream of their own, so that K1 of a later step fills the
+    # ramp-up and the tail of K5 / K7 of the current one (all three only stream through HBM)
+    pre = torch.cuda.Stream(priority=-1) if os.environ.get("GHF_BENCH_K1_STREAM", "0") == "1" else main
     # Steps in flight.  Steady state needs three; more let the main stream count the first inputs while the FIRST step's
     # one-wave code build (nothing to overlap it with at the start of a run) is still going.
     DEPTH = int(os.environ.get("GHF_BENCH_DEPTH", "8"))
@@ -369,9 +372,11 @@ def main():
             k = i % DEPTH
             cx, h, c, side, b = ctxs[k], hists[k], codes[k], sides[i % NSIDE], sets[i % NSETS]
             comm = self.comms[i % NSIDE] if self.comms else None
-            cx.use_stream(main)
-            self.timed("histogram", i, record, main, lambda: cx.histogram(b.d_in, out=h))
-            ev_hist[k].record(main)
+            if pre is not main and i >= DEPTH:
+                pre.wait_event(ev_ready[k])  # this slot's previous step has priced its chunks (K4 read what K1 is about to overwrite)
+            cx.use_stream(pre)
+            self.timed("histogram", i, record, pre, lambda: cx.histogram(b.d_in, out=h))
+            ev_hist[k].record(pre)
             side.wait_event(ev_hist[k])
             cx.use_stream(side)
             if self.sharded:
@@ -540,7 +545,7 @@ def main():
                        "bytes_per_gpu": n, "compressed_bytes_per_gpu": comp_bytes, "parallelism": "shard%d" % world,
                        "collectives": "none" if world == 1 else "all_reduce(256 x i64) + all_gather(1 x i64) per step",
                        "world_size": world, "collective_path": coll_path, "backend": ("none" if world == 1 else ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (rehearsal)")),
-                       "buffer_sets": NSETS, "side_streams": NSIDE, "communicators": len(comms) if comms else 0,
+                       "buffer_sets": NSETS, "side_streams": NSIDE, "histogram_stream": "own" if pre is not main else "main", "communicators": len(comms) if comms else 0,
                        "pipeline": "steps software-pipelined, up to %d in flight (one ghf context each, %d side stream(s)), rotating over %d sets of {input, output, decoded, side-car} buffers: main stream = histogram of step i+%d, emit + decode of step i; side stream(s), ahead of the main one = histogram all-reduce, one-wave code build, chunk pricing, decode tables, offset all-gather" % (DEPTH, NSIDE, NSETS, DEPTH - 1)},
             "encode_GBps": round(n * world / (enc_ms * 1e-3) / 1e9, 3), "decode_GBps": round(n * world / (stage_ms["decode"] * 1e-3) / 1e9, 3),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

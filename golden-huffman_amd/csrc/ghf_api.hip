@@ -660,7 +660,7 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
   {
     constexpr int kBatch = 4;
     uint64_t passes = 0;
-    const uint32_t fn_stride = (max_len_hint >= 1 && max_len_hint <= 16) ? 16u : 32u;
+    const uint32_t fn_stride = (max_len_hint >= 1 && max_len_hint <= 16) ? 16u : (max_len_hint > 32 ? 64u : 32u);
     bool scanned = first_start >= fn_stride;  // (the scan follows entry offsets below its stride only)
     if (prefer_scan && !scanned) {
       launch_sync_scan(p, ws + o_scan, fn_stride, first_start, c->stream);
@@ -865,7 +865,7 @@ int ghf_crs_compress(ghf_ctx* c, const uint8_t* d_in, size_t n, uint8_t* d_out, 
   if ((rc = ghf_crs_build_code(c, c->d_hist, tree, c->d_code))) return rc;  // compressor.h:64, start bit -> d_u64[6]
   if ((rc = ghf_encode_plan(c, d_in, n, c->d_code, c->d_u64))) return rc;
   // compressor.h:72: the body right behind tree + two prefix bytes; no end mark, zero fill (flags = 0)
-  if ((rc = ghf_encode_emit(c, d_in, n, c->d_code, c->d_u64 + 6, 0, d_out, cap, index, c->d_u64 + 1))) return rc;
+  if ((rc = ghf_encode_emit(c, d_in, n, c->d_code, c->d_u64 + 6, GHF_EMIT_LONG_CODES, d_out, cap, index, c->d_u64 + 1))) return rc;
   launch_crs_finish(tree, c->d_u64, d_out, d_out_bytes, c->d_status, c->stream);  // compressor.h:70 + normal_huff_encoder.h:176-184
   GHF_HIP(c, hipGetLastError());
   return GHF_OK;
@@ -922,7 +922,7 @@ int ghf_crs_parse_header(const uint8_t* h, size_t n, ghf_tree* tree, size_t* tre
     if (sp == 0) break;
   }
   if (n_leaves < 2 || n_leaves > 256 || n_parents != n_leaves - 1) return GHF_E_FORMAT;
-  if (max_len > 32) return GHF_E_CODELEN;
+  if (max_len > 64) return GHF_E_CODELEN;  // (a tree that deep needs more than 2^44 input bytes)
   tree->n_leaves = n_leaves;
   tree->max_len = max_len;
   tree->tree_bytes = (uint32_t)pos;
@@ -960,7 +960,7 @@ int ghf_crs_decoded_size(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
     *n_out = 0;
     return GHF_OK;
   }
-  rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, 1, (size_t)-1);
+  rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, 1, (size_t)-1, 0, nullptr, nullptr, false, 64);  // (codes up to 64 bits)
   if (rc) return rc;
   *n_out = c->fidx.n_symbols;
   return GHF_OK;
@@ -986,7 +986,7 @@ int ghf_crs_sync_piece(ghf_ctx* c, const uint8_t* d_piece, size_t piece_bytes, u
     return GHF_OK;
   }
   int bad = 0;  // with the tree's tables "end mark" can only mean: bits that are no code
-  const int rc = rebuild_index_at(c, d_piece, piece_bytes, 0, end_bit, 2, (size_t)-1, first_bit, landing, &bad);
+  const int rc = rebuild_index_at(c, d_piece, piece_bytes, 0, end_bit, 2, (size_t)-1, first_bit, landing, &bad, false, 64);
   if (rc) return rc;
   if (bad) return fail(c, GHF_E_CORRUPT, "the .crs body holds bits that are no code");
   *n_symbols = c->fidx.n_symbols;
@@ -1010,7 +1010,7 @@ int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int
         if (d_out_bytes) launch_store_u64(d_out_bytes, nullptr, 0, c->stream);
         return GHF_OK;
       }
-      rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, 1, cap);
+      rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, 1, cap, 0, nullptr, nullptr, false, 64);
       if (rc) return rc;
     }
     c->fidx_stream = nullptr;

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_crs_decode_tables(const ghf_tree* __res
   const int tid = threadIdx.x;
   const int max_len = (int)tree->max_len;
   const uint32_t root = tree->root, nl = tree->n_leaves;
-  if (max_len < 1 || max_len > 32 || nl < 2 || nl > 256 || root < 256 || root >= 256 + nl - 1) {
+  if (max_len < 1 || max_len > 64 || nl < 2 || nl > 256 || root < 256 || root >= 256 + nl - 1) {
     if (tid == 0) latch_status(status, GHF_E_FORMAT);
     return;
   }
@@ -260,7 +260,7 @@ template <typename LT>
 __device__ __forceinline__ uint32_t dec_long(const LT& L, uint32_t hi, int lut_bits, int max_len) {
   if (L.kind == 1) {  // .crs: walk the tree from the root (huff_tree.cc:255-271); malformed trees end in "no symbol"
     uint32_t node = L.root;
-    for (int l = 1; l <= max_len; ++l) {
+    for (int l = 1; l <= max_len && l <= 32; ++l) {
       const uint32_t p = node - 256u;
       if (p >= 256u) break;
       node = ((hi >> (32 - l)) & 1u) ? L.tr[p] : L.tl[p];
@@ -273,6 +273,23 @@ __device__ __forceinline__ uint32_t dec_long(const LT& L, uint32_t hi, int lut_b
   while (l < max_len && hi < L.fcl[l]) ++l;
   const uint32_t k = L.sp[l] + ((hi - L.fcl[l]) >> (32 - l));
   return (k < GHF_NSYM ? (uint32_t)L.symbol[k] : 256u) | ((uint32_t)l << 16);
+}
+// the same walk over 64 stream bits: a .crs tree deeper than 32 (include/huff_tree.cc:157-170 keeps codes as strings; such a
+// tree needs more than 3.5 million input bytes).  The callers' windows hold at least 65 bits behind the cursor.
+template <typename LT>
+__device__ __forceinline__ uint32_t dec_long64(const LT& L, uint64_t hi, int max_len) {
+  uint32_t node = L.root;
+  for (int l = 1; l <= max_len; ++l) {
+    const uint32_t p = node - 256u;
+    if (p >= 256u) break;
+    node = ((hi >> (64 - l)) & 1ull) ? L.tr[p] : L.tl[p];
+    if (node < 256u) return node | ((uint32_t)l << 16);
+  }
+  return 256u | ((uint32_t)max_len << 16);
+}
+// the next 64 stream bits of a cursor {W: 64 bits, o < 32 of them consumed; nextw: the 32 bits behind W}
+__device__ __forceinline__ uint64_t window64(uint64_t W, uint32_t nextw, uint32_t o) {
+  return o ? ((W << o) | ((uint64_t)nextw >> (32u - o))) : W;
 }
 
 // big-endian word at logical byte address la of the padded input tiles
@@ -305,6 +322,13 @@ __device__ __forceinline__ uint32_t dec_lookup(const DecLut& T, uint32_t v) {
 template <typename LT>
 __device__ __forceinline__ uint32_t dec_long_entry(const LT& L, uint32_t v, int lut_bits, int max_len) {
   const uint32_t r = dec_long(L, v, lut_bits, max_len);  // sym | len << 16
+  return (r & 0xFFu) | ((r >> 16) << 8) | ((r & 0x100u) << 8);
+}
+// ... for a cursor whose code may be longer than 32 bits (o < 32: the refill in front of every lookup guarantees it)
+template <typename LT>
+__device__ __forceinline__ uint32_t dec_long_entry_at(const LT& L, uint64_t W, uint32_t nextw, uint32_t o, int lut_bits, int max_len) {
+  if (max_len <= 32) return dec_long_entry(L, (uint32_t)((W << o) >> 32), lut_bits, max_len);
+  const uint32_t r = dec_long64(L, window64(W, nextw, o), max_len);
   return (r & 0xFFu) | ((r >> 16) << 8) | ((r & 0x100u) << 8);
 }
 
@@ -421,14 +445,14 @@ __device__ __forceinline__ uint32_t dec_cold(const DecLds7& L, const DecIn<STAGE
   widx += 3;
   uint32_t acc = 0;
   auto one = [&]() -> uint32_t {
-    if (o >= 32u) {
+    while (o >= 32u) {  // (a code of up to 64 bits moves the cursor by up to two words)
       W = (W << 32) | nextw;
       o -= 32u;
       nextw = I.fetch(widx++);
     }
     const uint32_t v = (uint32_t)((W << o) >> 32);
     uint32_t ent = dec_lookup(T, v);
-    if (ent & kEntNone) ent = dec_long_entry(L, v, lut_bits, max_len);
+    if (ent & kEntNone) ent = dec_long_entry_at(L, W, nextw, o, lut_bits, max_len);
     o += (ent >> 8) & 0xFFu;
     return ent;
   };
@@ -704,7 +728,8 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
       g2 = ticket_group(t3);
     };
     auto is_hot = [&]() -> bool {  // wave-uniform
-      if (group + 1 >= ngroups || !out_aligned) return false;                   // the last group may be ragged / carries the end mark
+      if (group + 1 >= ngroups || !out_aligned || max_len > 32) return false;  // the last group may be ragged / carries the end mark;
+                                                                                // codes beyond 32 bits (a very deep .crs tree): one symbol at a time
       if (cur.span > (uint32_t)kDec7InBytes || cur.byte0 + cur.span > full_bytes) return false;
       return __ballot(cur.bad) == 0;
     };
@@ -784,20 +809,56 @@ struct K6Cursor {
       nextw = in_word(lin, la);
       la += 4u;
     }
+    if (lut_bits >= 0 && o >= 32u) {  // (only a code beyond 32 bits moves the cursor by two words)
+      W = (W << 32) | nextw;
+      o -= 32u;
+      nextw = in_word(lin, la);
+      la += 4u;
+    }
     const uint32_t v = (uint32_t)((W << o) >> 32);
     uint32_t ent = dec_lookup(T, v);
-    if (lut_bits >= 0 && (ent & kEntNone)) ent = dec_long_entry(L, v, lut_bits, max_len);
+    if (lut_bits >= 0 && (ent & kEntNone)) ent = dec_long_entry_at(L, W, nextw, o, lut_bits, max_len);
     o += (ent >> 8) & 0xFFu;
     return ent;
   }
+  // the same for a canonical code with at most TWO lengths (uniform bytes: 8 / 9 bits; 16 symbols: 4 / 5): which of the two a
+  // code has is one comparison of the next bits with the first code of the shorter length -- no table, no LDS round trip
+  // in the dependency chain (canonical_huff_encoder.cc:446-450: the first length whose left-justified first code is <= v).
+  // Returns length << 8 (| kEntEnd for the end mark): all that K6 ever asks of an entry.
+  __device__ __forceinline__ uint32_t step2(const uint8_t* lin, const struct K6Two& C);
 };
+struct K6Two {
+  uint32_t thr;      // first code of the shorter length, left-justified (0: one length only)
+  uint32_t lmin;     // the shorter length
+  uint32_t eof_lo;   // the end mark's code, left-justified ...
+  uint32_t eof_span; // ... and 2^(32 - its length): v - eof_lo < eof_span  <=>  the next code IS the end mark
+};
+__device__ __forceinline__ uint32_t K6Cursor::step2(const uint8_t* lin, const K6Two& C) {
+  if (o >= 32u) {
+    W = (W << 32) | nextw;
+    o -= 32u;
+    nextw = in_word(lin, la);
+    la += 4u;
+  }
+  const uint32_t v = (uint32_t)((W << o) >> 32);
+  const uint32_t len = C.lmin + (v < C.thr ? 1u : 0u);
+  o += len;
+  return (len << 8) | ((v - C.eof_lo < C.eof_span) ? kEntEnd : 0u);
+}
+// MODE 0: table + tree walk / linear extension, 1: the table resolves every code, 2: two lengths
+template <int MODE>
+__device__ __forceinline__ uint32_t k6_step(K6Cursor& c, const uint8_t* lin, const DecLds7& L, const DecLut& T, int lut_bits, int max_len,
+                                            const K6Two& C2) {
+  if (MODE == 2) return c.step2(lin, C2);
+  return c.step(lin, L, T, MODE == 1 ? -1 : lut_bits, max_len);
+}
 
 // stage the bits of 64 consecutive subsequences (+ look-ahead) of the body into the wave's padded tile (big-endian
 // words, zeros behind the stream); returns the bit offset of subsequence `sub0` inside the tile
 __device__ __forceinline__ uint32_t k6_stage(const SyncParams& P, uint64_t sub0, uint8_t* lin, uint32_t la0, int lane) {
   const uint64_t bit0 = P.body_bit0 + sub0 * kSubBits;
   const uint64_t byte0 = (bit0 >> 3) & ~15ull;
-  uint64_t byte1 = ((bit0 + 64ull * kSubBits + 7) >> 3) + 16;
+  uint64_t byte1 = ((bit0 + 64ull * kSubBits + 7) >> 3) + 32;  // look-ahead: a code of <= 64 bits that begins in the last subsequence + the cursor's three words
   if (byte1 > P.stream_bytes) byte1 = P.stream_bytes;
   const uint32_t span = byte1 > byte0 ? (uint32_t)(byte1 - byte0) : 0u;
   const uint8_t* src = P.stream + byte0;
@@ -818,6 +879,21 @@ __device__ __forceinline__ uint32_t k6_stage(const SyncParams& P, uint64_t sub0,
   return (uint32_t)(bit0 - byte0 * 8);
 }
 
+// the two-length facts of a canonical code (meaningless, and unused, for any other code): from the tables in LDS
+__device__ __forceinline__ K6Two k6_two(const DecLds7& L, int min_len, int max_len) {
+  K6Two C;
+  C.lmin = (uint32_t)min_len;
+  C.thr = max_len > min_len ? L.fcl[min_len & 31] : 0u;
+  // the end mark is the largest symbol, hence the LAST code of its length: it sits at the end of its length's run in symbol[]
+  int k = 0;
+  while (k < GHF_NSYM && L.symbol[k] != 256) ++k;
+  const int len = (max_len > min_len && k >= (int)L.sp[max_len & 31]) ? max_len : min_len;
+  const uint32_t code_left = L.fcl[len & 31] + (((uint32_t)k - L.sp[len & 31]) << ((32 - len) & 31));
+  C.eof_lo = k < GHF_NSYM ? code_left : 0xFFFFFFFFu;
+  C.eof_span = k < GHF_NSYM ? (1u << ((32 - len) & 31)) : 0u;
+  return C;
+}
+
 constexpr int kK6Threads = kDec7Threads;
 constexpr int kK6Waves = kDec7Waves;
 
@@ -831,6 +907,8 @@ constexpr int kK6Waves = kDec7Waves;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               \
   const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;            \
   const bool direct = P.dt->kind == 0 && max_len <= kDecLutBitsMax;        \
+  const int k6_mode = (P.dt->kind == 0 && max_len - P.dt->min_len <= 1 && max_len <= 31) ? 2 : (direct ? 1 : 0); \
+  const K6Two C2 = k6_two(L, P.dt->min_len, max_len);                      \
   const DecLut T1 = dec7_lut1(L, P.dt, lane);                              \
   uint8_t* const lin = L.in;                                               \
   const uint32_t la0 = (uint32_t)wave * kDec7TileLog;                      \
@@ -844,8 +922,8 @@ __device__ __forceinline__ uint32_t k6_limit(uint64_t body_bits, uint64_t g) {  
 
 __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
   GHF_K6_PROLOGUE();
-  auto run = [&](auto direct_tag) {
-  const int lb = decltype(direct_tag)::value ? -1 : lut_bits;
+  auto run = [&](auto mode_tag) {
+  constexpr int MODE = decltype(mode_tag)::value;
   for (uint64_t g = (uint64_t)blockIdx.x * kK6Waves + wave; g < ngroups; g += (uint64_t)gridDim.x * kK6Waves) {
     const uint64_t sub = g * 64 + lane;
     const bool valid = sub < P.nsub;
@@ -869,7 +947,7 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
       K6Cursor cur;
       cur.open(lin, la0, base + pos);
       while (pos < sub_hi && pos < limit) {
-        const uint32_t ent = cur.step(lin, L, T1, lb, max_len);
+        const uint32_t ent = k6_step<MODE>(cur, lin, L, T1, lut_bits, max_len, C2);
         if (ent & kEntEnd) {  // the end mark (or bits that are no code)
           eof = true;
           break;
@@ -896,8 +974,9 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
     }
   }
   };
-  if (direct) run(std::true_type{});
-  else run(std::false_type{});
+  if (k6_mode == 2) run(std::integral_constant<int, 2>{});
+  else if (k6_mode == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
 }
 
 // ---- K6 for streams that do not self-synchronise quickly (near-fixed-length codes: uniform bytes have 8/9-bit codes and a
@@ -907,15 +986,15 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
 // enters each subsequence is the running composition of those functions -- a parallel scan over function composition
 // (64-ary tree: reduce up, apply down).  The result only seeds start[]: the fixed-point passes then verify it in one
 // pass (and would repair it), so no format subtlety (end mark, end of a .crs, stream pieces) lives here.
-// A function is STRIDE bytes (16 when max_len <= 16, else 32): entry s = landing offset in the next subsequence.
+// A function is STRIDE bytes (16 when max_len <= 16, 32 up to 32, else 64): entry s = landing offset in the next subsequence.
 //
 // k_sync_table: lane = subsequence, its max_len chains five at a time -- independent shift -> lookup -> add
 // dependency chains per lane hide the LDS round trip that a single chain leaves exposed (four waves per SIMD do not).
 __global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint32_t stride, uint8_t* __restrict__ tab) {
   GHF_K6_PROLOGUE();
   const uint32_t S = (uint32_t)max_len < stride ? (uint32_t)max_len : stride;
-  auto run = [&](auto direct_tag) {
-  const int lb = decltype(direct_tag)::value ? -1 : lut_bits;
+  auto run = [&](auto mode_tag) {
+  constexpr int MODE = decltype(mode_tag)::value;
   for (uint64_t g = (uint64_t)blockIdx.x * kK6Waves + wave; g < ngroups; g += (uint64_t)gridDim.x * kK6Waves) {
     wave_sync();
     const uint32_t base = k6_stage(P, g * 64, lin, la0, lane);
@@ -941,7 +1020,7 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint
 #pragma unroll
         for (uint32_t j = 0; j < NC; ++j) {
           if (p[j] < hi) {
-            p[j] += (c[j].step(lin, L, T1, lb, max_len) >> 8) & 0xFFu;
+            p[j] += (k6_step<MODE>(c[j], lin, L, T1, lut_bits, max_len, C2) >> 8) & 0xFFu;
             any = true;
           }
         }
@@ -954,13 +1033,14 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint
     }
   }
   };
-  if (direct) run(std::true_type{});
-  else run(std::false_type{});
+  if (k6_mode == 2) run(std::integral_constant<int, 2>{});
+  else if (k6_mode == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
 }
 
 // one level up: out[t] = f[64 t + 63] o ... o f[64 t]  (entry s: where a decode that enters tile t at offset s leaves it)
 __global__ __launch_bounds__(64) void k_fn_reduce(const uint8_t* __restrict__ f, uint64_t n, uint32_t stride, uint8_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint8_t fl[64 * 32];
+  __shared__ __attribute__((aligned(16))) uint8_t fl[64 * 64];
   const uint64_t t = blockIdx.x;
   const int lane = threadIdx.x;
   const uint64_t first = t * 64;
@@ -980,7 +1060,7 @@ __global__ __launch_bounds__(64) void k_fn_reduce(const uint8_t* __restrict__ f,
 template <typename OutT>
 __global__ __launch_bounds__(64) void k_fn_apply(const uint8_t* __restrict__ f, uint64_t n, uint32_t stride,
                                                  const uint8_t* __restrict__ tile_start, uint32_t entry, OutT* __restrict__ start) {
-  __shared__ __attribute__((aligned(16))) uint8_t fl[64 * 32];
+  __shared__ __attribute__((aligned(16))) uint8_t fl[64 * 64];
   __shared__ uint8_t st[64];
   const uint64_t t = blockIdx.x;
   const int lane = threadIdx.x;
@@ -1007,7 +1087,7 @@ size_t sync_scan_workspace(uint64_t nsub) {
     if (n <= 1) break;
     n = (n + 63) / 64;
   }
-  return (size_t)(total * (32 + 1) + 256 * 32);  // functions (<= 32 bytes) + entry offsets of every level, each level 256-aligned
+  return (size_t)(total * (64 + 1) + 256 * 32);  // functions (<= 64 bytes) + entry offsets of every level, each level 256-aligned
 }
 
 static uint32_t k6_blocks(uint64_t nsub) {
@@ -1077,8 +1157,8 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_index(SyncParams P, uint
   __shared__ unsigned long long wsum[kK6Waves];
   const uint64_t eof_sub = *P.eof_sub;
   const uint64_t ntrips = (P.nsub + kK6Threads - 1) / kK6Threads;
-  auto run = [&](auto direct_tag) {
-  const int lb = decltype(direct_tag)::value ? -1 : lut_bits;
+  auto run = [&](auto mode_tag) {
+  constexpr int MODE = decltype(mode_tag)::value;
   for (uint64_t trip = blockIdx.x; trip < ntrips; trip += gridDim.x) {
     const uint64_t g = trip * kK6Waves + wave;  // this wave's group of 64 subsequences
     const uint64_t sub = g * 64 + lane;
@@ -1112,13 +1192,14 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_index(SyncParams P, uint
         ++seg;
         mark += 64u;
       }
-      pos += (cur.step(lin, L, T1, lb, max_len) >> 8) & 0xFFu;
+      pos += (k6_step<MODE>(cur, lin, L, T1, lut_bits, max_len, C2) >> 8) & 0xFFu;
     }
     if (c && first + c == n_symbols) seg_abs[n_segs] = abs0 + pos;  // where the last data symbol ends
   }
   };
-  if (direct) run(std::true_type{});
-  else run(std::false_type{});
+  if (k6_mode == 2) run(std::integral_constant<int, 2>{});
+  else if (k6_mode == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
 }
 
 // seg_abs[s] = stream bit of symbol 64 s (s < n_segs), seg_abs[n_segs] = end of the last symbol  ->  the side-car K5 emits:

@@ -288,7 +288,7 @@ struct EmitMode {
                                                uint32_t (&l)[4]) {
     items_narrow(tab, (uint32_t)lane & 31u, v, cnt, q, l);
   }
-  static __device__ __forceinline__ void one(const uint32_t* tab, int lane, uint32_t byte, uint32_t& code, uint32_t& len) {
+  static __device__ __forceinline__ void one(const uint32_t* tab, int lane, uint32_t byte, uint64_t& code, uint32_t& len) {
     const uint32_t e = tab[(byte << 5) | ((uint32_t)lane & 31u)];
     code = e & 0xFFFFu;
     len = e >> 16;
@@ -302,10 +302,35 @@ struct EmitMode<0> {
                                                uint32_t (&l)[8]) {
     items_wide(reinterpret_cast<const uint64_t*>(tab), (uint32_t)lane & 15u, v, cnt, q, l);
   }
-  static __device__ __forceinline__ void one(const uint32_t* tab, int lane, uint32_t byte, uint32_t& code, uint32_t& len) {
+  static __device__ __forceinline__ void one(const uint32_t* tab, int lane, uint32_t byte, uint64_t& code, uint32_t& len) {
     const uint64_t e = reinterpret_cast<const uint64_t*>(tab)[(byte << 4) | ((uint32_t)lane & 15u)];
     code = (uint32_t)e;
     len = (uint32_t)(e >> 32);
+  }
+};
+// MODE 4 (k_emit_long): codes of 33..64 bits -- a .crs tree deeper than 32, which takes more than 3.5 million input bytes of
+// Fibonacci-distributed counts (huff_tree.cc:157-170 keeps codes as strings of any length).  `tab` is the ghf_code itself, in
+// global memory: length[], codeword[] = bits 0..31, symbol[] = bits 32..63 (k_crs_build_code).  One symbol per item.
+template <>
+struct EmitMode<4> {
+  static constexpr int NI = 16;
+  static constexpr int ML = 64;
+  static __device__ __forceinline__ void one(const uint32_t* tab, int lane, uint32_t byte, uint64_t& code, uint32_t& len) {
+    (void)lane;
+    len = tab[byte];
+    code = ((uint64_t)tab[2 * GHF_NSYM + byte] << 32) | tab[GHF_NSYM + byte];
+  }
+  static __device__ __forceinline__ void items(const uint32_t* tab, int lane, const uint4& v, uint32_t cnt, uint64_t (&q)[16],
+                                               uint32_t (&l)[16]) {
+    const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      one(tab, lane, (vv[i >> 2] >> (8 * (i & 3))) & 0xFFu, q[i], l[i]);
+      if ((uint32_t)i >= cnt) {
+        q[i] = 0;
+        l[i] = 0;
+      }
+    }
   }
 };
 
@@ -316,7 +341,16 @@ __device__ __forceinline__ uint32_t emit_tile(WaveOut& W, const uint64_t (&q)[Em
                                               const uint32_t (&l)[EmitMode<MODE>::NI], int lane, uint32_t* seg_out,
                                               bool seg_valid, uint32_t relbits, uint64_t* blk_dst, uint64_t blk_val) {
   constexpr int NI = EmitMode<MODE>::NI;
-  if constexpr (MODE != 0) {
+  if constexpr (MODE == 4) {  // 16 lanes x 16 items x 64 bits per pass
+    uint32_t* const seg_dst = (seg_out && seg_valid && (lane & 3) == 3) ? seg_out : nullptr;
+    uint32_t total = 0;
+#pragma unroll 1
+    for (int h = 0; h < 4; ++h) {
+      const bool mine = (lane >> 4) == h;
+      total += emit_items<NI, false>(W, q, l, mine, lane, mine ? seg_dst : nullptr, relbits + total, h == 0 ? blk_dst : nullptr, blk_val);
+    }
+    return total;
+  } else if constexpr (MODE != 0) {
     uint32_t* seg_dst = seg_out;
     if (KIND == 0) seg_dst = (seg_out && seg_valid && (lane & 3) == 3) ? seg_out : nullptr;  // stored with the tile's units
     return emit_window<EmitMode<MODE>::ML, KIND>(W, q, l, lane, seg_dst, relbits, blk_dst, blk_val);
@@ -342,7 +376,7 @@ template <int MODE>
 __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& G, uint32_t c, const uint32_t* tab,
                                            uint32_t* flat, uint32_t* st, int lane) {
   typedef EmitMode<MODE> M;
-  constexpr bool WIDE = MODE == 0;
+  constexpr bool WIDE = MODE == 0 || MODE == 4;  // the deposit-by-OR paths
   constexpr int NI = M::NI;
   const uint64_t chunk = P.chunk;
   const uint64_t sym0 = (uint64_t)c * chunk;
@@ -387,22 +421,28 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
   // ---- the bits in front of this chunk's first code that share its first 16-byte unit
   if (W.carry) {
     if (c > 0) {
-      uint32_t c0, l0, c1, l1;
+      uint64_t c0, c1;
+      uint32_t l0, l1;
       M::one(tab, lane, prev0, c0, l0);
       M::one(tab, lane, prev1, c1, l1);
-      uint64_t pr = ((uint64_t)c0 << l1) | c1;
-      uint32_t lp = l0 + l1;
+      const uint32_t lp = l0 + l1;
       const uint32_t incl = wave_incl_scan_u32(lp);
       const uint32_t after = wave_last_u32(incl) - incl;     // bits of the lanes behind me
-      const int end = (int)W.carry - (int)after;             // my pair ends here (staging bits)
-      int start = end - (int)lp;
-      if (end > 0) {
-        if (start < 0) {  // only the pair's last `end` bits are inside the unit
-          lp = (uint32_t)end;
-          pr &= ~0ull >> (64u - lp);
-          start = 0;
+      int end = (int)W.carry - (int)after;                   // my second symbol ends here (staging bits)
+#pragma unroll
+      for (int k = 1; k >= 0; --k) {                         // the second symbol, then the first in front of it
+        uint64_t cc = k ? c1 : c0;
+        uint32_t ll = k ? l1 : l0;
+        int start = end - (int)ll;
+        if (end > 0 && ll) {
+          if (start < 0) {  // only the code's last `end` bits are inside the unit
+            ll = (uint32_t)end;
+            cc &= ~0ull >> (64u - ll);
+            start = 0;
+          }
+          deposit64(flat, W.bit0 + (uint32_t)start, cc, ll);
         }
-        deposit64(flat, W.bit0 + (uint32_t)start, pr, lp);
+        end -= (int)(k ? l1 : l0);
       }
     } else if (!(P.flags & GHF_EMIT_REBASE)) {
       // chunk 0 of a buffer that starts at stream byte 0: bytes in front of the first code stay (the .crs2 header's
@@ -535,16 +575,15 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
   }
 }
 
-__global__ __launch_bounds__(kEmitThreads, 6) void k_emit(EmitParams P) {
-  __shared__ __attribute__((aligned(16))) uint32_t tab[kEmitTabWords];
-  __shared__ __attribute__((aligned(16))) uint32_t stage[kEmitWaves * kStageWords];
-  __shared__ int status0;
+// what both kernels start with: a failed earlier stage or an output that does not fit -> uniform exit; where the stream ends.
+// `mine` = this kernel is the one that packs codes of this length (the other one of the pair leaves without a trace).
+__device__ __forceinline__ bool emit_begin(const EmitParams& P, EmitGeom& G, int* status0, bool long_kernel) {
   const int tid = threadIdx.x;
-  if (tid == 0) status0 = *P.status;  // a previous stage failed -> uniform exit
+  if (tid == 0) *status0 = *P.status;  // a previous stage failed -> uniform exit
   __syncthreads();
-  if (status0 != 0) return;
-  EmitGeom G;
+  if (*status0 != 0) return false;
   G.max_len = P.code->max_len;
+  if ((G.max_len > 32) != long_kernel) return false;
   G.start_bit = P.d_start_bit ? *P.d_start_bit : 8ull * (1040ull + 8ull * (uint64_t)G.max_len);
   G.origin_byte = (P.flags & GHF_EMIT_REBASE) ? ((G.start_bit >> 7) << 4) : 0ull;
   // where the stream ends; does it fit?  (every workgroup computes the same answer from the same few words)
@@ -563,12 +602,27 @@ __global__ __launch_bounds__(kEmitThreads, 6) void k_emit(EmitParams P) {
       P.d_end[1] = end_byte;
     }
   }
-  if (!fits) return;
+  return fits;
+}
+
+__global__ __launch_bounds__(kEmitThreads, 6) void k_emit(EmitParams P) {
+  __shared__ __attribute__((aligned(16))) uint32_t tab[kEmitTabWords];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kEmitWaves * kStageWords];
+  __shared__ int status0;
+  const int tid = threadIdx.x;
+  EmitGeom G;
+  if (!emit_begin(P, G, &status0, false)) {
+    // codes beyond 32 bits are k_emit_long's (queued behind this kernel when the caller said GHF_EMIT_LONG_CODES);
+    // without that flag nobody would pack them
+    if (status0 == 0 && P.code->max_len > 32 && !(P.flags & GHF_EMIT_LONG_CODES) && blockIdx.x == 0 && tid == 0)
+      latch_status(P.status, GHF_E_FORMAT);
+    return;
+  }
   const bool wide = G.max_len > 16;
   {
     // 4 slots per symbol, each 32 bytes of the symbol's 128-byte row: replicas 8 * (i & 3) .. (u32) or 4 * (i & 3) .. (u64).
     // The tables may be the caller's own: the packers below size their registers and the staging area by max_len.
-    bool bad = G.max_len > 32 || G.max_len < 1;
+    bool bad = G.max_len < 1;
     for (int i = tid; i < 1024; i += kEmitThreads) {
       const int s = i >> 2;
       const uint32_t code = P.code->codeword[s], len = P.code->length[s];
@@ -600,10 +654,33 @@ __global__ __launch_bounds__(kEmitThreads, 6) void k_emit(EmitParams P) {
   else emit_chunk<0>(P, G, c, tab, stage, st, lane);
 }
 
+// Codes of 33..64 bits (a .crs whose tree is deeper than 32).  Same chunks, same one-writer-per-unit layout, same
+// side-car; the tables are read from global memory (three L2-resident words per symbol) and every symbol is an item of its
+// own.  Rare and slow by design: it exists so that every stream the reference can write can be written here.
+__global__ __launch_bounds__(kEmitThreads) void k_emit_long(EmitParams P) {
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kEmitWaves * kStageWords];
+  __shared__ int status0;
+  const int tid = threadIdx.x;
+  EmitGeom G;
+  if (!emit_begin(P, G, &status0, true)) return;
+  bool bad = G.max_len > 64 || (P.flags & GHF_EMIT_LAST) != 0;  // (no end mark in this format; 64 + 7 bits would not fit an item)
+  for (int s = tid; s < 256; s += kEmitThreads) bad |= P.code->length[s] > (uint32_t)G.max_len;
+  if (__syncthreads_or(bad)) {
+    if (tid == 0) latch_status(P.status, GHF_E_FORMAT);
+    return;
+  }
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t c = blockIdx.x * kEmitWaves + wave;
+  if (c >= P.nchunks) return;
+  emit_chunk<4>(P, G, c, reinterpret_cast<const uint32_t*>(P.code), stage, stage + wave * kStageWords, lane);
+}
+
 void launch_emit(const EmitParams& p, hipStream_t s) {
   const uint32_t blocks = (p.nchunks + kEmitWaves - 1) / kEmitWaves;
   if (blocks == 0) return;
   hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(kEmitThreads), 0, s, p);
+  if (p.flags & GHF_EMIT_LONG_CODES) hipLaunchKernelGGL(k_emit_long, dim3(blocks), dim3(kEmitThreads), 0, s, p);
 }
 
 }  // namespace ghf

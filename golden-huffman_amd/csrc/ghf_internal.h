@@ -127,7 +127,7 @@ void launch_sync_pass(const SyncParams& p, hipStream_t s);
 void launch_sync_counts(const SyncParams& p, uint64_t* d_total, hipStream_t s);
 // deterministic seeding of p.start[] (function-composition scan); ws = sync_scan_workspace(p.nsub) bytes, 256-byte aligned
 size_t sync_scan_workspace(uint64_t nsub);
-void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride /* 16: max_len <= 16 is known; else 32 */,
+void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride /* 16: max_len <= 16 is known; 64: it may exceed 32 (.crs); else 32 */,
                       uint32_t entry /* bit at which the first code begins, < stride */, hipStream_t s);
 void launch_sync_index(const SyncParams& p, uint64_t* d_seg_abs, uint64_t n_symbols, uint64_t* d_chunk_bit, uint32_t* d_seg_bit,
                        hipStream_t s);

@@ -658,6 +658,7 @@ struct TreeLds {
   uint16_t tl[256], tr[256];             // children of merge t (tree node ids of HeapLds: 0..255 leaves, 257 + t merges)
   uint16_t size[GHF_NSYM + 256 + 7];     // nodes in the subtree
   uint8_t is_right[GHF_NSYM + 256 + 7];  // the node is its parent's right child
+  uint32_t code_hi[256];                 // bits 32..63 of a leaf's code
   uint32_t max_len, min_len;
   int n;
 };
@@ -734,9 +735,10 @@ __global__ __launch_bounds__(64) void k_crs_build_code(const unsigned long long*
       tree.header[2 * pre + 1] = (uint8_t)v;
       atomicMax(&T.max_len, len);
       atomicMin(&T.min_len, len);
-      if (len <= 32) {
+      if (len <= 64) {
         out_code->length[v] = len;
         out_code->codeword[v] = (uint32_t)code;
+        T.code_hi[v] = (uint32_t)(code >> 32);
       }
     } else {
       tree.header[2 * pre] = 255;          // huff_tree.cc:183-184
@@ -747,20 +749,24 @@ __global__ __launch_bounds__(64) void k_crs_build_code(const unsigned long long*
       tree.right[t] = (uint16_t)(b < GHF_NSYM ? b : 256 + (b - GHF_NSYM));
     }
   }
-  // symbols that do not occur, the end-mark slot and the canonical-only tables of ghf_code
+  __syncthreads();
+  // symbols that do not occur, the end-mark slot and the canonical-only tables of ghf_code.  A tree deeper than 32
+  // (huff_tree.cc:157-170 keeps codes as strings of any length) puts bits 32..63 of every code into symbol[], which this
+  // format has no other use for: K5's long-code kernel reads them there.
+  const bool deep = T.max_len > 32u;
   for (int s = lane; s < GHF_NSYM; s += 64) {
-    if (s == 256 || heap.parent[s] == 0) {
+    const bool absent = s == 256 || heap.parent[s] == 0;
+    if (absent) {
       out_code->length[s] = 0;
       out_code->codeword[s] = 0;
     }
-    out_code->symbol[s] = 0xFFFFFFFFu;
+    out_code->symbol[s] = deep ? (absent ? 0u : T.code_hi[s]) : 0xFFFFFFFFu;
   }
   for (int i = lane; i < 64; i += 64) {
     out_code->first_code[i] = 0;
     out_code->start_pos[i] = 0;
   }
-  __syncthreads();
-  if (T.max_len > 32u) {  // K5 packs codes of at most 32 bits
+  if (T.max_len > 64u) {  // (needs more than 2^44 input bytes: Fibonacci counts)
     if (lane == 0) latch_status(status, GHF_E_CODELEN);
     return;
   }

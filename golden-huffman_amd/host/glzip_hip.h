@@ -772,11 +772,13 @@ class PieceEncoder {
   //   last_flags        : GHF_EMIT_LAST for a stream that ends with the end mark (end_mark_bits long) and 1-padding
   //   out_bytes_        : the size the counts give (header + every byte that holds a bit of the body): checked
   // Returns the stream's end bit; last_byte_ <- the stream byte that holds its last bit.
-  uint64_t emit_pieces(const ghf_code* dc, const uint8_t* head, size_t head_bytes, int last_flags, uint32_t end_mark_bits) {
+  //   more_flags        : GHF_EMIT_LONG_CODES when the code has words of more than 32 bits (a .crs tree deeper than 32)
+  uint64_t emit_pieces(const ghf_code* dc, const uint8_t* head, size_t head_bytes, int last_flags, uint32_t end_mark_bits,
+                       int more_flags = 0) {
     pipe().begin();
     const Session &run = pipe().run(), &out = pipe().out();
     const size_t P = pipe().piece(), np = (n_ + P - 1) / P;
-    const size_t cap = ghf_shard_bound(P);
+    const size_t cap = ghf_shard_bound(P) * ((more_flags & GHF_EMIT_LONG_CODES) ? 2 : 1);  // up to 32 (64) bits per symbol
     for (int r = 0; r < kRing; ++r)
       if (d_out_[r].n < cap) d_out_[r].alloc(run, cap);
     if (!d_scal_.p) d_scal_.alloc(run, kRing * 4 * sizeof(uint64_t));
@@ -821,7 +823,7 @@ class PieceEncoder {
       hs[4 * r + 1] = start;
       run.check(ghf_copy_h2d(run.ctx(), ds + 4 * r + 1, const_cast<uint64_t*>(hs + 4 * r + 1), sizeof(uint64_t)), "ghf_copy_h2d");
       fetched_[r].hold(run);  // the D2H of piece k - kRing has let go of d_out_[r]
-      run.check(ghf_encode_emit(run.ctx(), src, len, dc, ds + 4 * r + 1, GHF_EMIT_REBASE | (last ? last_flags : 0), d_out_[r].u8(), cap,
+      run.check(ghf_encode_emit(run.ctx(), src, len, dc, ds + 4 * r + 1, GHF_EMIT_REBASE | more_flags | (last ? last_flags : 0), d_out_[r].u8(), cap,
                                 NULL, ds + 4 * r + 2),
                 "ghf_encode_emit");  // K5
       used_[r].record(run);
@@ -1266,6 +1268,7 @@ class HipNormalHuffEncoder<unsigned char> : private detail::PieceEncoder {
     run.sync("gen_encode");
     body_bits_ = 0;  // the body's size follows from the counts: the output file is sized up front
     for (int b = 0; b < 256; ++b) body_bits_ += hist[b] * code.length[b];
+    long_codes_ = code.max_len > 32;
     out_bytes_ = (size_t)tree_.tree_bytes + 2 + (size_t)((body_bits_ + 7) >> 3);
   }
 
@@ -1288,7 +1291,7 @@ class HipNormalHuffEncoder<unsigned char> : private detail::PieceEncoder {
       head[hdr - 2] = head[hdr - 1] = 0;
       if (fwrite(head + hdr - 2, 1, 2, outfile_) != 2) throw Error(GHF_E_INVAL, "short write (prefix)");
       fflush(outfile_);
-      const uint64_t end = emit_pieces(static_cast<const ghf_code*>(d_code_.p), head, hdr, 0, 0);
+      const uint64_t end = emit_pieces(static_cast<const ghf_code*>(d_code_.p), head, hdr, 0, 0, long_codes_ ? GHF_EMIT_LONG_CODES : 0);
       if (end != 8 * (uint64_t)hdr + body_bits_) throw Error(GHF_E_CORRUPT, "encode_file: the pieces do not add up to the bits the counts give");
       const size_t whole = (size_t)(body_bits_ >> 3);
       const unsigned left = (unsigned)((8 - (body_bits_ & 7)) & 7);
@@ -1307,6 +1310,7 @@ class HipNormalHuffEncoder<unsigned char> : private detail::PieceEncoder {
  private:
   detail::DeviceBuf d_tree_, d_code_;
   uint64_t body_bits_ = 0;
+  bool long_codes_ = false;  // some code has more than 32 bits (the tree is deeper than 32)
   ghf_tree tree_;
 };
 

@@ -154,6 +154,10 @@ size_t ghf_header_bytes(int max_len); /* 1040 + 8*max_len */
 #define GHF_EMIT_LAST 1
 #define GHF_EMIT_REBASE 2
 #define GHF_EMIT_HEADER 4 /* also write the .crs2 header at d_out[0..) (same bytes as ghf_write_header; not with REBASE) */
+#define GHF_EMIT_LONG_CODES 8 /* the tables may hold codes of 33..64 bits (ghf_crs_build_code on a tree deeper than 32:
+                                 include/huff_tree.cc:157-170 keeps codes as strings of any length): a second, slower kernel
+                                 is queued behind the packer and does the work when the first one finds such a code.  The
+                                 canonical format never has them (include/canonical_huff_encoder.h:43-44). */
 int ghf_encode_plan(ghf_ctx* ctx, const uint8_t* d_in, size_t n, const ghf_code* d_code, uint64_t* d_total_bits);
 int ghf_encode_emit(ghf_ctx* ctx, const uint8_t* d_in, size_t n, const ghf_code* d_code, const uint64_t* d_start_bit,
                     int flags, uint8_t* d_out, size_t cap, const ghf_index* index, uint64_t* d_end);
@@ -281,8 +285,10 @@ int ghf_compress_ex(ghf_ctx* ctx, const uint8_t* d_in, size_t n, uint8_t* d_out,
  * no end mark), the Huffman TREE itself defines the codes ('0' = left = first popped, '1' = right), the file is
  *   [tree in preorder, 2 bytes per node: (0, key) leaf / (255, 255) parent] [left_bits] [last byte] [whole body bytes]
  * The kernels are the ones above (K1, K4, K5, K7, K6); only the code assignment and the framing differ.
- * Codes longer than 32 bits are refused (GHF_E_CODELEN) although the reference, which keeps them as strings, could
- * write them: they need > 3.5 M input bytes arranged like Fibonacci numbers.
+ * The reference keeps codes as strings of any length (include/huff_tree.cc:157-170): a tree deeper than 32 -- more than
+ * 3.5 M input bytes with counts arranged like Fibonacci numbers -- is packed by a second, slower kernel
+ * (GHF_EMIT_LONG_CODES) and decoded by a 64-bit tree walk.  Depths beyond 64 (> 2^44 input bytes) are refused
+ * (GHF_E_CODELEN).
  * ------------------------------------------------------------------------------------------------ */
 
 /* The tree as NormalHuffEncoder builds it (EncodeHuffTree, include/huff_tree.h:175-262) and NormalHuffDecoder
@@ -293,13 +299,14 @@ typedef struct ghf_tree {
   uint16_t right[256];
   uint32_t root;        /* node id; >= 256 (a tree that is a single leaf is refused) */
   uint32_t n_leaves;    /* 2 .. 256 */
-  uint32_t max_len;     /* depth of the deepest leaf, <= 32 */
+  uint32_t max_len;     /* depth of the deepest leaf, <= 64 */
   uint32_t tree_bytes;  /* 2 * (2 * n_leaves - 1) */
   uint8_t header[1024]; /* the preorder serialisation (tree_bytes of it), huff_tree.cc:174-187 */
 } ghf_tree;
 
 /* EncodeHuffTree::build_tree + gen_encode + serialize_tree (include/huff_tree.cc:138-187) on one wavefront.
- * d_hist: ghf_histogram()'s output (slot [256] is ignored).  d_code receives length[] / codeword[] for K4/K5. */
+ * d_hist: ghf_histogram()'s output (slot [256] is ignored).  d_code receives length[] / codeword[] for K4/K5; when the
+ * tree is deeper than 32, codeword[] holds bits 0..31 of every code and symbol[] bits 32..63 (else symbol[] = 0xFFFFFFFF). */
 int ghf_crs_build_code(ghf_ctx* ctx, const uint64_t* d_hist, ghf_tree* d_tree, ghf_code* d_code);
 
 /* Compressor<NormalHuffEncoder<>>::compress() (include/compressor.h:62-73, normal_huff_encoder.h:136-186).
@@ -310,7 +317,7 @@ int ghf_crs_compress(ghf_ctx* ctx, const uint8_t* d_in, size_t n, uint8_t* d_out
 size_t ghf_crs_compress_bound(size_t n);
 
 /* DecodeHuffTree::build_tree (include/huff_tree.cc:289-303) on the host, with the checks the reference lacks
- * (truncated / over-long / degenerate trees -> GHF_E_FORMAT, depth > 32 -> GHF_E_CODELEN).  *tree_bytes <- size of
+ * (truncated / over-long / degenerate trees -> GHF_E_FORMAT, depth > 64 -> GHF_E_CODELEN).  *tree_bytes <- size of
  * the serialised tree; the two prefix bytes {left_bits, last byte} follow it (normal_huff_encoder.h:163-164). */
 int ghf_crs_parse_header(const uint8_t* h_stream, size_t n, ghf_tree* tree, size_t* tree_bytes);
 

@@ -65,6 +65,16 @@ CASES = {
 }
 
 
+# `.crs` only: the reference's tree codes are strings of any length (include/huff_tree.cc:157-170), so a tree
+# deeper than 32 is reference-defined there -- while the canonical coder stops at 32 bits (canonical_huff_encoder.h:43-44).
+# 34 Fibonacci counts (24 157 815 bytes) -> depth 33.
+CRS_DEEP_CASES = {
+    "fib34_depth33": lambda: dg.counts_to_bytes(dg.fib_counts(34), seed=44),
+}
+CRS_CASES = dict(CASES)
+CRS_CASES.update(CRS_DEEP_CASES)
+
+
 def _sparse(a):
     """spread the used byte values over 0..255 (value v -> 13*v+5 mod 256)"""
     return ((a.astype(np.int64) * 13 + 5) % 256).astype(np.uint8)

@@ -21,7 +21,7 @@ ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 from oracle import oracle as orc  # noqa: E402
-from cases import CASES, INLINE_CRS2  # noqa: E402
+from cases import CRS_CASES as CASES, INLINE_CRS2  # noqa: E402  (the shared cases + the deep-tree ones)
 
 
 def sha(b):

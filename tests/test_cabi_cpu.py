@@ -132,13 +132,18 @@ def test_crs_parse_header_rejects_garbage(ghf, golden_crs):
     with pytest.raises(ghf.GhfError) as e:
         ghf.crs_parse_header(np.full(2000, 255, dtype=np.uint8))  # parents only, never closes
     assert e.value.status == 6
-    # a 40-deep comb: well-formed, but deeper than the 32-bit codes the kernels handle
-    comb = []
-    for d in range(40):
-        comb += [255, 255, 0, d]
-    comb += [0, 200]
+    # a 40-deep comb: well-formed, and within the 64 bits the long-code paths handle
+    def comb(depth):
+        c = []
+        for d in range(depth):
+            c += [255, 255, 0, d]
+        return np.array(c + [0, 200], dtype=np.uint8)
+
+    tree, tb = ghf.crs_parse_header(comb(40))
+    assert tree.max_len == 40 and tree.n_leaves == 41 and tb == 2 * (2 * 41 - 1)
+    # a 70-deep one: deeper than any code the kernels pack (it would take more than 2^44 input bytes)
     with pytest.raises(ghf.GhfError) as e:
-        ghf.crs_parse_header(np.array(comb, dtype=np.uint8))
+        ghf.crs_parse_header(comb(70))
     assert e.value.status == 4
 
 

@@ -8,7 +8,7 @@ import pytest
 
 import datagen as dg
 import pkgload
-from cases import CASES
+from cases import CRS_CASES as CASES
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -62,8 +62,10 @@ def test_crs_every_stage_matches_reference_fixture(env, golden_crs, name):
     assert tree.code_strings() == g["codes"]
     assert tree.tree_bytes == g["tree_bytes"] and bytes(tree.header[: tree.tree_bytes]) == base64.b64decode(g["tree_b64"])
     code = ctx.code_to_host(d_code)
+    deep = g["max_len"] > 32  # bits 32..63 of a code then sit in symbol[] (include/ghf.h, ghf_crs_build_code)
     for s, cs in enumerate(g["codes"]):
-        assert code.length[s] == len(cs) and (not cs or code.codeword[s] == int(cs, 2)), s
+        full = code.codeword[s] | ((code.symbol[s] << 32) if deep else 0)
+        assert code.length[s] == len(cs) and (not cs or full == int(cs, 2)), s
     # whole pipeline
     idx = ctx.index_alloc(data.size)
     d_out, nbytes, d_tree2 = ctx.crs_compress(d_in, index=idx)

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from cases import CASES
+from cases import CASES, CRS_CASES
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -218,10 +218,11 @@ def test_streaming_stager_multi_piece_file(tool, tmp_path):
     assert np.array_equal(np.fromfile(str(f) + ".crs2.de", dtype=np.uint8), data)
 
 
-@pytest.mark.parametrize("name", ["aaaabbc", "ab", "all256_once", "zipf_64k", "fib32_maxlen32", "uniform_65537", "sym16_n1003"])
+@pytest.mark.parametrize("name", ["aaaabbc", "ab", "all256_once", "zipf_64k", "fib32_maxlen32", "uniform_65537", "sym16_n1003", "fib34_depth33"])
 def test_crs_mode_switch_compress_then_decompress(tool, tmp_path, golden_crs, name):
-    """modes 1 / 2 of unit_tests/test.cc:295-301: Compressor<NormalHuffEncoder<>> / Decompressor<NormalHuffDecoder<>>"""
-    data = CASES[name]()
+    """modes 1 / 2 of unit_tests/test.cc:295-301: Compressor<NormalHuffEncoder<>> / Decompressor<NormalHuffDecoder<>>
+    (fib34_depth33: codes of up to 33 bits -- the long-code kernel and the 64-bit tree walk through the file pipeline)"""
+    data = CRS_CASES[name]()
     f = tmp_path / (name + ".bin")
     data.tofile(f)
     assert subprocess.run([tool, str(f), "1"], timeout=120).returncode == 0

@@ -8,7 +8,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from cases import CASES
+from cases import CRS_CASES as CASES
 from oracle import oracle as orc
 import datagen as dg
 
