@@ -13,7 +13,7 @@ one global code via an RCCL all-reduce of the 256-bin histogram and an all-gathe
 
 Steps in flight work on DIFFERENT buffers: GHF_BENCH_SETS (default 3) sets of {input, output, decoded, side-car}, each with
 its own synthetic data, rotate with the step number.  A watchdog thread ends the run with the name of the stuck stage when
-no stage completes for GHF_BENCH_STEP_TIMEOUT seconds (default 120) -- a collective that never returns must not sit there
+no stage completes for GHF_BENCH_STEP_TIMEOUT seconds (default 180) -- a collective that never returns must not sit there
 until the driver's limit.
 
 Rank 0 prints ONE JSON line.  `value` = input GB (1e9 B) pushed through encode+decode per second by the
@@ -261,7 +261,7 @@ def main():
     ghf = pkg.ghf
     from golden_huffman_amd import synth
 
-    wd = Watchdog(float(os.environ.get("GHF_BENCH_STEP_TIMEOUT", "120")), rank)
+    wd = Watchdog(float(os.environ.get("GHF_BENCH_STEP_TIMEOUT", "180")), rank)
     hang_at = os.environ.get("GHF_BENCH_INJECT_HANG", "")  # "<rank>:<step>": that rank never joins that step's all-reduce (tests)
     ctx = ghf.Context(local_rank)
     n = args.mib << 20

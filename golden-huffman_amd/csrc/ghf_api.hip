@@ -668,11 +668,13 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
     }
     for (;;) {
       if (passes > p.nsub + 2) return fail(c, GHF_E_CORRUPT, "self-synchronisation did not converge");
-      for (int b = 0; b < kBatch; ++b) {
+      // (behind the deterministic scan the first pass only has to CONFIRM the boundaries: one pass, not a batch)
+      const int nb = (scanned && passes == 0) ? 1 : kBatch;
+      for (int b = 0; b < nb; ++b) {
         GHF_HIP(c, hipMemsetAsync(p.changed, 0, 8, c->stream));
         launch_sync_pass(p, c->stream);
       }
-      passes += kBatch;
+      passes += nb;
       GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 5, p.changed, 8, hipMemcpyDeviceToHost, c->stream));
       GHF_HIP(c, hipStreamSynchronize(c->stream));
       if ((uint32_t)c->h_u64[5] == 0) break;

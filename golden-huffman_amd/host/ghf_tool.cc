@@ -111,9 +111,14 @@ static int file_to_file_perf() {
   fclose(f);
   double c_ms[3], d_ms[3];
   for (int i = 0; i < 3; ++i) {
-    // fresh output files each time: truncating a multi-GiB file in /dev/shm costs as much as writing a third of it
-    remove((infile_name + ".crs2").c_str());
-    remove((infile_name + ".crs2.de").c_str());
+    // fresh output files each time: truncating a multi-GiB file in /dev/shm costs as much as writing a third of it.
+    // GHF_SINK=reuse: the files of the first round stay and are written over (their pages exist: the sink is then
+    // bound by the copies, not by the kernel's page allocation)
+    const char* how = getenv("GHF_SINK");
+    if (!(how && strcmp(how, "reuse") == 0)) {
+      remove((infile_name + ".crs2").c_str());
+      remove((infile_name + ".crs2.de").c_str());
+    }
     double t0 = now_ms();
     canonical_huff_char_compress(infile_name);
     c_ms[i] = now_ms() - t0;

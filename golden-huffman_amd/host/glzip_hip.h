@@ -28,6 +28,7 @@
 #include <string.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <chrono>
 #include <condition_variable>
@@ -311,6 +312,22 @@ struct Jobs {  // the pool jobs that still use a pinned buffer
   }
 };
 
+// The output file.  Default: created / emptied ("w+b", what the reference's fopen(.., "wb") does).  GHF_SINK=reuse: an
+// existing file is opened as it is -- its pages stay, and the sink copies into them instead of making new ones (a new
+// file in /dev/shm is bound by the kernel's page allocation, 20 GB/s at best; see the sink notes in Pipe); the file is cut to
+// its final size at the end either way.
+inline bool sink_reuses() {
+  const char* how = getenv("GHF_SINK");
+  return how && strcmp(how, "reuse") == 0;
+}
+inline FILE* open_output(const std::string& name) {
+  if (sink_reuses()) {
+    FILE* f = fopen(name.c_str(), "r+b");
+    if (f) return f;
+  }
+  return fopen(name.c_str(), "w+b");
+}
+
 class Pipe {
  public:
   static const int kSlots = 6;  // per ring; a ring is used first-in first-out
@@ -437,7 +454,12 @@ class Pipe {
     const size_t made = pre_fd_ == fd ? pre_done_.load() : 0;
     pre_fd_ = -1;
     if (!wants_map(bound)) return;
-    if (ftruncate(fd, (off_t)bound) != 0) return;
+    size_t have = 0;  // GHF_SINK=reuse: what the file already holds counts as made pages (the caller's promise: no holes)
+    if (sink_reuses()) {
+      struct stat st;
+      if (fstat(fd, &st) == 0 && st.st_size > 0) have = (size_t)st.st_size & ~(size_t)4095;
+    }
+    if (have < bound && ftruncate(fd, (off_t)bound) != 0) return;
     sized_ = true;
     void* m = mmap(NULL, bound, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     if (m == MAP_FAILED) return;
@@ -445,6 +467,7 @@ class Pipe {
     unmapped_ = 0;
     const size_t end = (bound + 4095) & ~(size_t)4095;
     ready_ = made < end ? made : end;
+    if (have > ready_) ready_ = have < end ? have : end;
     if (exact) (void)reserve(bound, true);
   }
   // Pages for [0, bytes) of the file that open_sink() is given next, made by a pool thread from now on: the encoder
@@ -452,6 +475,7 @@ class Pipe {
   // and page-making is the slowest stage of the output side.  cancel_presize() before the file is closed.
   void presize(int fd, size_t bytes) {
     cancel_presize();
+    if (sink_reuses()) return;  // (the pages are there; what is missing is made by reserve())
     if (!wants_map(bytes) || env_bytes("GHF_IO_THREADS", 12) < 3) return;  // (it would sit in front of the reads in the queue)
     pre_fd_ = fd;
     pre_done_ = 0;
@@ -482,7 +506,7 @@ class Pipe {
   }
   static bool wants_map(size_t bound) {
     const char* how = getenv("GHF_SINK");
-    return how ? strcmp(how, "mmap") == 0 : bound >= ((size_t)8 << 20);
+    return how ? (strcmp(how, "mmap") == 0 || strcmp(how, "reuse") == 0) : bound >= ((size_t)8 << 20);
   }
   // the driver knows the final size by now (the decoder, once everything is decoded): make the rest of the pages at once
   void reserve_all(size_t bytes) { (void)reserve(bytes, true); }
@@ -702,7 +726,7 @@ class PieceEncoder {
     infile_ = fopen(infile_name.c_str(), "rb");
     if (!infile_) throw Error(GHF_E_INVAL, "cannot open input file " + infile_name);
     if (outfile_name.empty()) outfile_name = infile_name + ext;
-    outfile_ = fopen(outfile_name.c_str(), "w+b");  // read-write: the pipeline maps it
+    outfile_ = detail::open_output(outfile_name);  // read-write: the pipeline maps it
     if (!outfile_) throw Error(GHF_E_INVAL, "cannot open output file " + outfile_name);
   }
   void close_files() {  // include/encoder.h:85-92
@@ -912,7 +936,7 @@ class PieceDecoder {
     infile_ = fopen(infile_name.c_str(), "rb");
     if (!infile_) throw Error(GHF_E_INVAL, "cannot open input file " + infile_name);
     if (outfile_name.empty()) outfile_name = infile_name + ".de";
-    outfile_ = fopen(outfile_name.c_str(), "w+b");  // read-write: the pipeline maps it
+    outfile_ = detail::open_output(outfile_name);  // read-write: the pipeline maps it
     if (!outfile_) {
       fclose(infile_);
       throw Error(GHF_E_INVAL, "cannot open output file " + outfile_name);

@@ -1,7 +1,7 @@
-"""gpurun_out/<tag>/ (written by scratch/profile_r02.sh on the GPU box) -> profiles/<out>/: the bench line, the
+"""gpurun_out/<tag>/ (written by scratch/profile_r03.sh on the GPU box) -> profiles/<out>/: the bench line, the
 rocprofv3 kernel-stats summaries, one table per input size with every PMC counter averaged per kernel and the HBM
 bytes derived from them, the pipeline trace summaries, the file-to-file rates; and profiles/traffic.json.
-usage: python scratch/collect_r02.py r02 r02_a"""
+usage: python scratch/collect_r03.py r03 r03_a"""
 import collections
 import csv
 import glob
@@ -54,7 +54,7 @@ for mib, name in ((256, "256MiB"), (4096, "4GiB")):
             row.append(hb)
             w.writerow(row)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-for f in ("pipe_summary_resident.txt", "pipe_summary_streamed.txt", "file_perf.json", "file_perf_with_reread.json"):
+for f in ("file_perf.json", "membench.txt", "bench_zipf.json", "bench_sym16.json", "bench_4GiB_uniform.json", "bench_4GiB_zipf.json"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 print(open(os.path.join(ROOT, "profiles", "traffic.json")).read())

@@ -39,11 +39,19 @@ def main():
         with tempfile.TemporaryDirectory(dir="/dev/shm", prefix="ghf_") as d:
             f = os.path.join(d, kind + ".bin")
             make(kind, n).tofile(f)
-            for env_extra in [{}] + ([{"GHF_RESIDENT_BYTES": "0"}] if os.environ.get("GHF_PERF_REREAD") else []):
+            # default sink (a NEW output file every round: bound by the kernel's page allocation), then GHF_SINK=reuse (the
+            # output files of the first round are written over: their pages exist), optionally without keeping the input in HBM
+            variants = [("", {}), ("_reuse", {"GHF_SINK": "reuse"})]
+            if os.environ.get("GHF_PERF_REREAD"):
+                variants.append(("_reread", {"GHF_RESIDENT_BYTES": "0"}))
+            for suffix, env_extra in variants:
                 env = dict(os.environ)
                 env.update(env_extra)
+                for g in (f + ".crs2", f + ".crs2.de"):
+                    if os.path.exists(g):
+                        os.remove(g)
                 r = subprocess.run([TOOL, f, "7"], capture_output=True, text=True, timeout=1200, env=env)
-                key = kind + ("_reread" if env_extra else "")
+                key = kind + suffix
                 try:
                     res[key] = json.loads(r.stdout.strip().splitlines()[-1])
                 except Exception:

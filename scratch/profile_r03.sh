@@ -1,14 +1,14 @@
 #!/bin/bash
-# scratch/profile_r02.sh <tag> -- everything profiles/<tag>/ is made from, on the GPU box (one gpurun call):
+# scratch/profile_r03.sh <tag> -- everything profiles/<tag>/ is made from, on the GPU box (one gpurun call):
 #   bench JSON (default command), rocprofv3 kernel stats of the same command, PMC passes (HBM traffic, SQ/LDS) at
-#   256 MiB and at 4 GiB uniform, the file pipeline's trace summary in both modes, the file-to-file rates.
-TAG=${1:-r02}
+#   256 MiB and at 4 GiB uniform, the memory microbenchmark, the file-to-file rates (new output file / reused output file).
+TAG=${1:-r03}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp
-echo "== bench (default command)"; python3 $R/bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json; echo
+echo "== bench (default command)"; python3 $R/bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json; echo
 echo "== kernel stats 256 MiB"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats256 -- python3 $R/bench.py --steps 100 --warmup 3 --no-cpu-baseline --no-configs > $O/stats256.log 2>&1 || echo "stats256 failed"
 echo "== kernel stats 4 GiB"
@@ -24,13 +24,10 @@ for MIB in 256 4096; do
   done
 done
 cd $R
-echo "== pipeline trace (output resident in HBM / streamed through the rings)"
-timeout -k 10 300 bash scratch/pipe_trace.sh 1024 > $O/pipe_resident.log 2>&1; cp gpurun_out/pipe/summary.txt $O/pipe_summary_resident.txt
-GHF_RESIDENT_BYTES=0 timeout -k 10 300 bash scratch/pipe_trace.sh 1024 > $O/pipe_streamed.log 2>&1; cp gpurun_out/pipe/summary.txt $O/pipe_summary_streamed.txt
-rm -rf gpurun_out/pipe
+echo "== memory microbenchmark"
+timeout -k 10 300 ./scratch/membench > $O/membench.txt 2>&1
 echo "== file to file"
-timeout -k 10 400 python3 scratch/file_perf.py 4 uniform zipf > $O/file_perf.log 2>&1; cp gpurun_out/file_perf.json $O/file_perf.json
-GHF_PERF_REREAD=1 timeout -k 10 400 python3 scratch/file_perf.py 4 zipf > $O/file_perf_reread.log 2>&1; cp gpurun_out/file_perf.json $O/file_perf_with_reread.json
+timeout -k 10 600 python3 scratch/file_perf.py 4 uniform zipf > $O/file_perf.log 2>&1; cp gpurun_out/file_perf.json $O/file_perf.json
 # raw per-dispatch traces are large; keep stats and counter files only
 find $O -name '*kernel_trace.csv' -size +1M -delete
 find $O -name '*.db' -delete
