@@ -994,23 +994,27 @@ void launch_shard_start(const ghf_code* d_code, const uint64_t* d_totals, int ra
 
 // ------------------------------------------------------------------------------------------------
 // Bandwidth probe (ghf_copy_d2d): what a kernel that only MOVES bytes reaches with this path's own access shape --
-// 16 bytes per lane, four loads in flight per lane, one resident round of workgroups, optional non-temporal hints.
-// bench.py prices the codec kernels against it (and against the 8 TB/s of the data sheet).
+// 16 bytes per lane, four loads in flight per lane, every workgroup streaming through a contiguous slab of its own (what
+// K5's and K7's waves do with their chunks and groups), optional non-temporal hints.  Of the shapes scratch/membench.hip
+// tries this is the fastest on MI355X (4 GiB: 5.3-5.5 TB/s of read + write; grid-stride with the same loads 4.6-4.9;
+// profiles/r03/membench.txt).  bench.py prices the codec kernels against it (and against the 8 TB/s of the data sheet).
 // ------------------------------------------------------------------------------------------------
 template <bool NT>
 __global__ __launch_bounds__(256) void k_stream_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t nvec) {
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t per = (nvec + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * per;
+  const uint64_t end = lo + per < nvec ? lo + per : nvec;
+  uint64_t i = lo + threadIdx.x;
   auto ld = [&](uint64_t k) -> uint4 { return NT ? load_stream(src + k) : src[k]; };
   auto st = [&](uint64_t k, const uint4& v) {
     if (NT) store_stream(dst + k, v);
     else dst[k] = v;
   };
-  for (; i + 3 * stride < nvec; i += 4 * stride) {
-    const uint4 a = ld(i), b = ld(i + stride), c = ld(i + 2 * stride), d = ld(i + 3 * stride);
-    st(i, a); st(i + stride, b); st(i + 2 * stride, c); st(i + 3 * stride, d);
+  for (; i + 3 * 256 < end; i += 4 * 256) {
+    const uint4 a = ld(i), b = ld(i + 256), c = ld(i + 512), d = ld(i + 768);
+    st(i, a); st(i + 256, b); st(i + 512, c); st(i + 768, d);
   }
-  for (; i < nvec; i += stride) st(i, ld(i));
+  for (; i < end; i += 256) st(i, ld(i));
 }
 __global__ void k_tail_copy(const uint8_t* src, uint8_t* dst, uint64_t from, uint64_t n) {
   const uint64_t i = from + threadIdx.x;
@@ -1020,7 +1024,7 @@ void launch_stream_copy(const uint8_t* d_src, uint8_t* d_dst, uint64_t n, bool n
   const uint64_t nvec = n / 16;
   if (nvec) {
     uint64_t blocks = (nvec + 255) / 256;
-    if (blocks > 2048) blocks = 2048;  // 8 workgroups of 4 waves per CU: one resident round
+    if (blocks > 4096) blocks = 4096;  // slabs: 16 workgroups of 4 waves per CU
     if (nt) hipLaunchKernelGGL(k_stream_copy<true>, dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(d_src), reinterpret_cast<uint4*>(d_dst), nvec);
     else hipLaunchKernelGGL(k_stream_copy<false>, dim3((uint32_t)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(d_src), reinterpret_cast<uint4*>(d_dst), nvec);
   }

@@ -638,3 +638,16 @@ def test_runs_of_the_longest_codes_at_max_len_11(env):
         ctx.sync()
         assert int(n3.item()) == part.size and np.array_equal(back3[: part.size].cpu().numpy(), part)
         ctx.index_free(idx)
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 4096 + 7, (1 << 20) + 3, (64 << 20) + 11])
+@pytest.mark.parametrize("nt", [True, False])
+def test_copy_probe_kernel_copies(env, n, nt):
+    """ghf_copy_d2d (bench.py's bandwidth probe) is a copy: every size, ragged tails, both cache policies"""
+    ghf, ctx, torch = env
+    src = torch.randint(0, 256, (max(n, 1) + 32,), dtype=torch.uint8, device="cuda")
+    dst = torch.full((max(n, 1) + 32,), 0xA5, dtype=torch.uint8, device="cuda")
+    ctx.copy_d2d(dst, src, n, non_temporal=nt)
+    ctx.sync()
+    assert bool((dst[:n] == src[:n]).all().item())
+    assert bool((dst[n:] == 0xA5).all().item())  # nothing behind the end is touched
