@@ -268,7 +268,7 @@ def main():
     bound = ghf.compress_bound(n) if world == 1 else ghf.shard_bound(n)
     # Buffer sets: steps in flight work on different inputs and write different outputs.  Set s of rank r is the byte range
     # [(s * world + r) * n, +n) of one long synthetic stream, so that (for every s) the ranks' shards are consecutive.
-    NSETS = max(1, int(os.environ.get("GHF_BENCH_SETS", "3")))
+    NSETS = max(1, int(os.environ.get("GHF_BENCH_SETS", "3" if os.environ.get("GHF_BENCH_MAINS", "1") == "1" else "4")))
 
     class BufSet:
         pass
@@ -301,6 +301,11 @@ def main():
     # GHF_BENCH_K1_STREAM=1: the histograms get a high-priority stream of their own, so that K1 of a later step fills the
     # ramp-up and the tail of K5 / K7 of the current one (all three only stream through HBM)
     pre = torch.cuda.Stream(priority=-1) if os.environ.get("GHF_BENCH_K1_STREAM", "0") == "1" else main
+    # GHF_BENCH_MAINS=2 (experiment): even and odd steps pack and decode on two high-priority streams, so that one step's K5
+    # fills the tail of the other's K7.  Needs an even number of buffer sets and of steps in flight (a set / a context slot
+    # is then always used from the same stream).  Per-kernel durations are measured under that overlap.
+    NMAIN = int(os.environ.get("GHF_BENCH_MAINS", "1"))
+    mains = [main] + [torch.cuda.Stream(priority=-1) for _ in range(NMAIN - 1)]
     # Steps in flight.  Steady state needs three; more let the main stream count the first inputs while the FIRST step's
     # one-wave code build (nothing to overlap it with at the start of a run) is still going.
     DEPTH = int(os.environ.get("GHF_BENCH_DEPTH", "8"))
@@ -411,13 +416,14 @@ def main():
                 cx, c, b = ctxs[k], codes[k], sets[i % NSETS]
                 if i + ahead < K:
                     self.front(i + ahead, rec_of(i + ahead))
-                main.wait_event(ev_ready[k])
-                cx.use_stream(main)
+                mstream = mains[i % NMAIN]
+                mstream.wait_event(ev_ready[k])
+                cx.use_stream(mstream)
                 start_bit = t_start[k] if self.sharded else None
                 flags = sharded_flags if self.sharded else local_flags
                 b.index.flags = (0 if last_rank else ghf.INDEX_NO_END_MARK) if self.sharded else 0
-                self.timed("emit", i, rec_of(i), main, lambda: cx.encode_emit(b.d_in, c, b.out, start_bit=start_bit, flags=flags, index=b.index, end=b.end))
-                self.timed("decode", i, rec_of(i), main, lambda: cx.decode(b.out, bound, c, b.index, d_out=b.dec, nbytes=t_nbytes))
+                self.timed("emit", i, rec_of(i), mstream, lambda: cx.encode_emit(b.d_in, c, b.out, start_bit=start_bit, flags=flags, index=b.index, end=b.end))
+                self.timed("decode", i, rec_of(i), mstream, lambda: cx.decode(b.out, bound, c, b.index, d_out=b.dec, nbytes=t_nbytes))
 
         def measure(self, K, barrier):
             """time exactly K steps: barrier + synchronize on both sides"""

@@ -320,3 +320,23 @@ def test_code_limit_opt_in_through_the_host_layer(tool, tmp_path):
     if orc.have_ref():
         orc.ref_run(["d", str(f) + ".crs2", str(tmp_path / "ref.de")], timeout=300)
         assert np.array_equal(np.fromfile(tmp_path / "ref.de", dtype=np.uint8), data)
+
+
+def test_sink_reuse_writes_over_an_existing_output_file(tool, tmp_path):
+    """GHF_SINK=reuse: the output file is not emptied first, its pages are written over and it is cut to the new size at the
+    end -- a LARGER old file must not leave a tail, a SMALLER one must grow; both directions, .crs2 equal to the oracle's"""
+    import datagen as dg
+
+    big = dg.zipf_bytes((24 << 20) + 333, seed=5)
+    small = dg.uniform_bytes((9 << 20) + 17, seed=6)
+    f = tmp_path / "x.bin"
+    env = _env(GHF_SINK="reuse", GHF_IO_THREADS=4)
+    for data in (big, small, big):
+        data.tofile(f)
+        assert subprocess.run([tool, str(f), "3"], timeout=300, env=env).returncode == 0
+        crs = np.fromfile(str(f) + ".crs2", dtype=np.uint8)
+        ref = orc.compress(data)
+        assert crs.size == ref.size and np.array_equal(crs, ref)
+        assert subprocess.run([tool, str(f) + ".crs2", "4"], timeout=300, env=env).returncode == 0
+        back = np.fromfile(str(f) + ".crs2.de", dtype=np.uint8)
+        assert back.size == data.size and np.array_equal(back, data)
