@@ -36,7 +36,7 @@ struct ghf_ctx {
   const ghf_code* dt_code = nullptr;  // ghf_decode_prepare() built d_dt from these tables; consumed by the next ghf_decode
   uint64_t* d_totals = nullptr;  // [totals_cap] per-rank body bits (ghf_encode_sharded)
   int totals_cap = 0;
-  uint64_t* d_u64 = nullptr;    // [8] scratch scalars: 0 total_bits, 1..2 end, 3 n_symbols, 4 eof_sub, 5 changed
+  uint64_t* d_u64 = nullptr;    // [16] scratch scalars: 0 total_bits, 1..2 end, 3 n_symbols, 4 eof_sub, 5 changed, 6 start bit (.crs), 8 landing
   uint64_t* h_u64 = nullptr;    // [8] pinned mirror
   // K6 workspace (foreign streams)
   void* d_sync = nullptr;
@@ -162,8 +162,8 @@ int ghf_ctx_create(int device, ghf_ctx** out) {
   GHF_STEP(hipMalloc(&c->d_code, sizeof(ghf_code)));
   GHF_STEP(hipMalloc(&c->d_tree, sizeof(ghf_tree)));
   GHF_STEP(hipMalloc(&c->d_dt, sizeof(DecTables)));
-  GHF_STEP(hipMalloc(&c->d_u64, 8 * sizeof(uint64_t)));
-  GHF_STEP(hipHostMalloc(&c->h_u64, 8 * sizeof(uint64_t), hipHostMallocDefault));
+  GHF_STEP(hipMalloc(&c->d_u64, 16 * sizeof(uint64_t)));
+  GHF_STEP(hipHostMalloc(&c->h_u64, 16 * sizeof(uint64_t), hipHostMallocDefault));
   GHF_STEP(hipMemset(c->d_status, 0, sizeof(int)));
 #undef GHF_STEP
   if (e != hipSuccess) {
@@ -643,20 +643,20 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
   p.changed = reinterpret_cast<uint32_t*>(c->d_u64 + 5);
   p.eof_sub = c->d_u64 + 4;
   GHF_HIP(c, hipMemsetAsync(p.start, 0, (p.nsub + 1) * 2, c->stream));
-  if (first_start) {
-    const uint16_t fs = (uint16_t)first_start;
-    GHF_HIP(c, hipMemcpyAsync(p.start, &fs, 2, hipMemcpyHostToDevice, c->stream));
-    GHF_HIP(c, hipStreamSynchronize(c->stream));  // fs lives on this stack frame
-  }
+  if (first_start) launch_store_u64(reinterpret_cast<uint64_t*>(p.start), nullptr, first_start, c->stream);  // start[0] (the three
+                                                                                                          // guesses behind it stay 0)
   GHF_HIP(c, hipMemsetAsync(p.used, 0xFF, p.nsub * 2, c->stream));
   GHF_HIP(c, hipMemsetAsync(p.eof, 0, p.nsub, c->stream));
-  launch_store_u64(p.eof_sub, nullptr, p.nsub, c->stream);  // "none found"; k_sync_eof takes the minimum
   // passes until no boundary guess moves (self-synchronisation: a handful of passes in practice).  They are queued in
-  // batches and the host looks at the "something moved" word of a batch's LAST pass only: one round trip per batch instead of
-  // one per pass (a pass that finds nothing to do reads 4 bytes per subsequence and stages nothing)
+  // batches; behind every batch the counts (first end mark, symbols per tile, their scan) and the landing bit are queued as
+  // well, and the host reads {symbols, end-mark subsequence, "something moved", landing} in ONE round trip: a stream that has
+  // settled in its first batch -- the usual case, and the rule behind the deterministic scan -- costs one synchronisation (round 2:
+  // four per call, a quarter of the file decompressor's K6 time at 16 MiB pieces).
   // Streams that self-synchronise slowly (near-fixed-length codes) would need one pass per subsequence of drift: their
   // boundaries are seeded by the deterministic scan (launch_sync_scan) -- at once when the caller knows the code is of that
   // kind, otherwise as soon as a first batch of passes has not settled.  The passes then only verify.
+  uint64_t n = 0, eof_sub = 0;
+  uint16_t land16 = 0;
   {
     constexpr int kBatch = 4;
     uint64_t passes = 0;
@@ -675,7 +675,10 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
         launch_sync_pass(p, c->stream);
       }
       passes += nb;
-      GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 5, p.changed, 8, hipMemcpyDeviceToHost, c->stream));
+      launch_store_u64(p.eof_sub, nullptr, p.nsub, c->stream);  // "none found"; k_sync_eof takes the minimum
+      launch_sync_counts(p, c->d_u64 + 3, c->stream);
+      launch_load_u16(c->d_u64 + 8, p.start + p.nsub, c->stream);
+      GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 3, c->d_u64 + 3, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       GHF_HIP(c, hipStreamSynchronize(c->stream));
       if ((uint32_t)c->h_u64[5] == 0) break;
       if (!scanned) {
@@ -683,24 +686,17 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
         scanned = true;
       }
     }
+    n = c->h_u64[3];
+    eof_sub = c->h_u64[4];
+    land16 = (uint16_t)c->h_u64[8];
   }
-  launch_sync_counts(p, c->d_u64 + 3, c->stream);
-  GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 3, c->d_u64 + 3, 16, hipMemcpyDeviceToHost, c->stream));
-  GHF_HIP(c, hipStreamSynchronize(c->stream));
-  const uint64_t n = c->h_u64[3], eof_sub = c->h_u64[4];
   if (no_eof) {
     // every subsequence counts; a flagged one means bits that are no code or a code running past the end
     // (eof_sub == nsub, "none", makes the counting kernels take every subsequence: n is already the total)
     if (eof_sub < p.nsub) return fail(c, GHF_E_CORRUPT, "the .crs body does not end on a code boundary");
   } else if (mode == 2) {
     if (has_end_mark) *has_end_mark = eof_sub < p.nsub;
-    if (landing) {
-      uint16_t l = 0;
-      GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 5, p.start + p.nsub, 2, hipMemcpyDeviceToHost, c->stream));
-      GHF_HIP(c, hipStreamSynchronize(c->stream));
-      std::memcpy(&l, c->h_u64 + 5, 2);
-      *landing = l == 0xFFFF ? 0 : l;  // 0xFFFF: the last subsequence ended at an end mark (real, or a fake one of a wrong guess)
-    }
+    if (landing) *landing = land16 == 0xFFFF ? 0 : land16;  // 0xFFFF: the last subsequence ended at an end mark (real, or a fake one of a wrong guess)
   } else if (eof_sub >= p.nsub) {
     return fail(c, GHF_E_CORRUPT, "no end mark in the stream");
   }

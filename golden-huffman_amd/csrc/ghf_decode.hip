@@ -242,14 +242,26 @@ __device__ __forceinline__ uint32_t dec7_entry(uint32_t g) {  // DecTables::lut 
 // replicated fill: one-symbol table, entry idx, copy r at lut[(idx << rlog) | r]; with a pair table (small alphabets)
 // the 64 KiB hold lut2 (two symbols per entry) and the one-symbol table goes into the small region behind it
 __device__ __forceinline__ void dec_lds_load7(DecLds7& L, const DecTables* dt, int tid, int nthreads) {
+  // (every table has at least four copies of an entry side by side: 16 bytes per store, a quarter of the round trips --
+  //  this prologue is paid by every launch of K7 and of the K6 kernels, several per file piece)
   const int pb = dt->pair_bits, lb = dt->lut_bits;
+  uint4* const lut4 = reinterpret_cast<uint4*>(L.lut);
   if (pb) {
     const int r2 = (kDec7LutLog2 - pb) < 5 ? (kDec7LutLog2 - pb) : 5;
-    for (int i = tid; i < (1 << (pb + r2)); i += nthreads) L.lut[i] = dt->lut2[i >> r2];
-    for (int i = tid; i < kDec7SmallSlots; i += nthreads) L.lut[kDec7LutSlots + i] = dec7_entry(dt->lut[(i >> 5) & ((1 << lb) - 1)]);
+    for (int g = tid; g < (1 << (pb + r2 - 2)); g += nthreads) {
+      const uint32_t e = dt->lut2[(4 * g) >> r2];
+      lut4[g] = make_uint4(e, e, e, e);
+    }
+    for (int g = tid; g < kDec7SmallSlots / 4; g += nthreads) {
+      const uint32_t e = dec7_entry(dt->lut[((4 * g) >> 5) & ((1 << lb) - 1)]);
+      lut4[kDec7LutSlots / 4 + g] = make_uint4(e, e, e, e);
+    }
   } else {
     const int r1 = (kDec7LutLog2 - lb) < 5 ? (kDec7LutLog2 - lb) : 5;
-    for (int i = tid; i < (1 << (lb + r1)); i += nthreads) L.lut[i] = dec7_entry(dt->lut[i >> r1]);
+    for (int g = tid; g < (1 << (lb + r1 - 2)); g += nthreads) {
+      const uint32_t e = dec7_entry(dt->lut[(4 * g) >> r1]);
+      lut4[g] = make_uint4(e, e, e, e);
+    }
   }
   dec_small_load(L, dt, tid, nthreads);
 }

@@ -16,10 +16,11 @@ constexpr int kBlockSymbols = 4096;     // side-car block = 64 segments = one K7
 // A chunk = the input one K5 wave packs (and the unit K1 prices for K4).  Chunks are sized so that ALL of them are resident
 // at once: K5 keeps 3 workgroups x 8 waves on each of the 256 CUs, and a grid of 1.33 rounds (8192 power-of-two chunks, as in
 // round 1) spends its last third with a third of the waves -- too few loads in flight to keep HBM busy.  Multiples of
-// 16 KiB (four rounds of K1's 4 KiB vector rows), at most 1 MiB.  (Round 3 tried 2 workgroups x 16 waves, 8 waves per SIMD:
+// 4 KiB (K1's vector rows: 256 threads x 16 bytes; K5's trips of four 1 KiB tiles), at least 16 KiB, at most 1 MiB.  (Round 3 tried 2 workgroups x 16 waves, 8 waves per SIMD:
 // 3 % faster alone, 12 % slower between the other kernels of the pipelined bench -- a 1024-thread workgroup needs half a
 // CU to drain before it can start.)
-constexpr uint32_t kChunkQuantum = 16384;
+constexpr uint32_t kChunkQuantum = 4096;
+constexpr uint32_t kMinChunk = 16384;
 constexpr uint32_t kMaxChunk = 1u << 20;
 constexpr uint32_t kEmitSlots = 256 * 3 * 8;
 
@@ -40,7 +41,7 @@ constexpr int kDecLutBitsMax = 12;
 inline uint32_t chunk_symbols_for(uint64_t n) {
   const uint64_t per_slot = (n + kEmitSlots - 1) / kEmitSlots;
   uint64_t c = (per_slot + kChunkQuantum - 1) / kChunkQuantum * kChunkQuantum;
-  if (c < kChunkQuantum) c = kChunkQuantum;
+  if (c < kMinChunk) c = kMinChunk;
   if (c > kMaxChunk) c = kMaxChunk;
   return (uint32_t)c;
 }
@@ -152,6 +153,7 @@ void launch_crs_finish(const ghf_tree* d_tree, const uint64_t* d_total_bits, uin
 void launch_crs_decode_tables(const ghf_tree* d_tree, DecTables* d_dt, int* d_status, hipStream_t s);
 void launch_stream_copy(const uint8_t* d_src, uint8_t* d_dst, uint64_t n, bool nt, hipStream_t s);
 void launch_store_u64(uint64_t* d_dst, const uint64_t* d_src_opt, uint64_t add, hipStream_t s);
+void launch_load_u16(uint64_t* d_dst, const uint16_t* d_src, hipStream_t s);
 void launch_shard_start(const ghf_code* d_code, const uint64_t* d_totals, int rank, uint64_t* d_start_bit, hipStream_t s);
 
 }  // namespace ghf

@@ -70,9 +70,9 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
   // keeps a late or slow workgroup from becoming the kernel's straggler.  Per thread the vectors of consecutive
   // chunks form ONE stream: four 16-byte loads are always in flight (A/B and C/D alternate, no register copies),
   // also across the chunk boundary -- the next chunk's first vectors are requested while this one is reduced.
-  const uint32_t V = chunk32 >> 12;  // vectors per thread per chunk (256 threads x 16 B = 4 KiB), a multiple of 4
+  const uint32_t V = chunk32 >> 12;  // vectors per thread per chunk (256 threads x 16 B = 4 KiB); any count >= 4
   const uint32_t nfullchunks = (uint32_t)(n / chunk);
-  const bool fast = (V & 3u) == 0 && V != 0 && (((uintptr_t)in) & 15u) == 0 && nfullchunks > 0;
+  const bool fast = V >= 4u && (chunk32 & 4095u) == 0 && (((uintptr_t)in) & 15u) == 0 && nfullchunks > 0;
   if (fast) {
     const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;
     const uint32_t cls = blockIdx.x % ncls;
@@ -86,21 +86,41 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
       if (c >= nfullchunks) c = nfullchunks - 1;  // past the end: redundant, harmless loads
       return reinterpret_cast<const uint4*>(in + (uint64_t)c * chunk) + (uint64_t)j * kHistThreads + tid;
     };
+    // vector g of the thread's STREAM: the chunk's own vectors, then the next chunk's
+    auto vat = [&](uint32_t g) -> const uint4* { return g < V ? vptr(cur, g) : vptr(nxt, g - V); };
+    const uint32_t Vmain = V & ~3u, Vrest = V & 3u;  // (wave-uniform, the same for every chunk of the launch)
     // non-temporal loads: the input streams past the Infinity Cache instead of through it (4 GiB: 0.79 -> 0.69 ms, i.e.
     // 6.2 TB/s of reads; nothing changes at 256 MiB, where the pipelined neighbours' write-backs set the pace)
     uint4 A = load_stream(vptr(cur, 0)), B = load_stream(vptr(cur, 1));
     while (cur < nfullchunks) {
       uint32_t t_next = 0;
       if (tid == 0) t_next = draw();  // the chunk after next; the atomic returns long before it is needed
-      for (uint32_t j = 0; j < V; j += 4) {
-        const uint4 C = load_stream(vptr(cur, j + 2)), D = load_stream(vptr(cur, j + 3));
+      for (uint32_t j = 0; j < Vmain; j += 4) {
+        const uint4 C = load_stream(vat(j + 2)), D = load_stream(vat(j + 3));
         hist_vec(lh, rep, A);
         hist_vec(lh, rep, B);
-        const bool more = j + 4 < V;
-        A = load_stream(vptr(more ? cur : nxt, more ? j + 4 : 0));
-        B = load_stream(vptr(more ? cur : nxt, more ? j + 5 : 1));
+        A = load_stream(vat(j + 4));
+        B = load_stream(vat(j + 5));
         hist_vec(lh, rep, C);
         hist_vec(lh, rep, D);
+      }
+      // A, B = vectors Vmain, Vmain + 1 of the stream: the chunk's last one to three vectors, then the next chunk's first two
+      if (Vrest == 1u) {
+        hist_vec(lh, rep, A);
+        A = B;  // (was the next chunk's vector 0)
+        B = load_stream(vptr(nxt, 1));
+      } else if (Vrest == 2u) {
+        hist_vec(lh, rep, A);
+        hist_vec(lh, rep, B);
+        A = load_stream(vptr(nxt, 0));
+        B = load_stream(vptr(nxt, 1));
+      } else if (Vrest == 3u) {
+        const uint4 C = load_stream(vptr(cur, V - 1));
+        hist_vec(lh, rep, A);
+        hist_vec(lh, rep, B);
+        A = load_stream(vptr(nxt, 0));
+        B = load_stream(vptr(nxt, 1));
+        hist_vec(lh, rep, C);
       }
       if (tid == 0) s_tick = t_next;
       const uint32_t posted = finish_chunk(cur);
@@ -323,7 +343,7 @@ __device__ __forceinline__ u64t wave_heap_pop(HeapLds& h, int& n, int lane) {
   const int steps = D - 1 > 0 ? D - 1 : 0;
   t >>= 7 - steps;
   if (t <= lim) t = 2u * t + (uint32_t)(((t < 64u || t == 128u ? R0 : R1) >> (t & 63u)) & 1ull);  // depth D-1 where both children exist
-  if ((len & 1) == 0 && t == (uint32_t)len >> 1) t = 2u * t;  // lone left child of an even-length heap
+  t <<= (((uint32_t)len & 1u) ^ 1u) & (uint32_t)(t == ((uint32_t)len >> 1));  // lone left child of an even-length heap (kept in scalar arithmetic)
   const int k = 31 - __clz(t);  // depth of the hole
   // 3. lane j < k takes path node u_j = t >> (k - j): ONE more LDS read (the children pair of u_j) gives cv_j, the entry that
   //    __adjust_heap moves up into u_j (its preferred child, which is path node u_{j+1}).  __push_heap from the hole then moves
@@ -334,7 +354,7 @@ __device__ __forceinline__ u64t wave_heap_pop(HeapLds& h, int& n, int lane) {
   const uint32_t u = onp ? (t >> sh) : 1u;
   const U64x2 c = *reinterpret_cast<const U64x2*>(&h.slot[2 * u]);
   const u64t cv = ((t >> ((sh - 1u) & 31u)) & 1u) ? c.y : c.x;
-  const unsigned long long S = __ballot(onp && !heap_gt(cv, value));
+  const unsigned long long S = __ballot(!heap_gt(cv, value)) & ((1ull << k) - 1ull);  // lanes 0..k-1 are on the path
   const int m = S ? 64 - __clzll((long long)S) : 0;
   if (lane <= m) h.slot[lane < m ? u : (t >> ((uint32_t)(k - m) & 31u))] = lane < m ? cv : value;
   wave_sync();  // the next heap operation reads, in OTHER lanes, what these lanes stored (without the fence the compiler may
@@ -981,6 +1001,10 @@ __global__ void k_store_u64(uint64_t* dst, const uint64_t* src, uint64_t add) { 
 void launch_store_u64(uint64_t* d_dst, const uint64_t* d_src_opt, uint64_t add, hipStream_t s) {
   hipLaunchKernelGGL(k_store_u64, dim3(1), dim3(1), 0, s, d_dst, d_src_opt, add);
 }
+
+// *dst = *src for a 16-bit word (K6: the landing bit of a piece, fetched with the counts in one host round trip)
+__global__ void k_load_u16(uint64_t* dst, const uint16_t* src) { *dst = *src; }
+void launch_load_u16(uint64_t* d_dst, const uint16_t* d_src, hipStream_t s) { hipLaunchKernelGGL(k_load_u16, dim3(1), dim3(1), 0, s, d_dst, d_src); }
 
 // multi-GPU: this rank's absolute start bit = header bits + body bits of all lower ranks
 __global__ void k_shard_start(const ghf_code* code, const uint64_t* totals, int rank, uint64_t* start_bit) {

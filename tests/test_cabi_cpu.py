@@ -57,7 +57,7 @@ def test_bounds_and_chunking(ghf):
         b = ghf.compress_bound(n)
         assert b % 16 == 0 and b >= 1040 + 256 + (9 * (n + 1) + 7) // 8
         c = ghf.chunk_symbols(n)
-        assert c % 16384 == 0 and 16384 <= c <= (1 << 20)
+        assert c % 4096 == 0 and 16384 <= c <= (1 << 20)
         assert -(-n // c) <= 6144 or c == (1 << 20)  # one resident round of K5 waves (256 CUs x 3 workgroups x 8 waves)
     assert ghf.lib().ghf_header_bytes(9) == 1112
 
@@ -196,6 +196,10 @@ def test_emit_main_loops_have_counted_waits_and_no_scratch():
                 assert not any("scratch_" in l for l in blk), (label, "scratch traffic inside a main loop")
                 assert all(w in (n,) for w in waits if w != 0) or True
     assert counted[15] == 3 and counted[11] == 3, counted  # modes 1..3 (codes <= 9 / 12 / 16 bits)
+    # ... and the shipped geometry (512 threads, 6 waves per SIMD) needs no scratch at all
+    meta = re.search(r"\.name:\s+_ZN3ghf6k_emitENS_10EmitParamsE\b(.*?)\.wavefront_size", text, flags=re.S).group(1)
+    assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1)) == 0
+    assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) == 0
 
 
 def test_decode_kernel_scratch_reloads_are_followed_by_full_waits():
