@@ -80,7 +80,7 @@ struct EmitParams {
   const uint64_t* d_start_bit;
   uint8_t* out;
   uint64_t cap;
-  uint32_t chunk;       // symbols per chunk (a multiple of 16 KiB)
+  uint32_t chunk;       // symbols per chunk (a multiple of 4 KiB, >= 16 KiB)
   uint32_t nchunks;
   uint64_t* chunk_bit;  // side-car (may be null): [n / 4096] absolute start bit of every block
   uint32_t* seg_bit;    // side-car (may be null): [n / 64] end bit of every segment, relative to its block

@@ -651,3 +651,27 @@ def test_copy_probe_kernel_copies(env, n, nt):
     ctx.sync()
     assert bool((dst[:n] == src[:n]).all().item())
     assert bool((dst[n:] == 0xA5).all().item())  # nothing behind the end is touched
+
+
+@pytest.mark.parametrize("mib", [117, 130, 146, 200, 230])
+def test_histogram_exact_for_every_vector_count_remainder(env, mib):
+    """K1's fast path takes a chunk's 4 KiB vector rows four at a time and the last one to three separately: sizes whose
+    chunks have 5, 6, 7, 9 and 10 rows per thread (remainders 1, 2, 3, 1, 2), exact against torch's count, and
+    the per-chunk counts K4 prices from give the oracle's bit total"""
+    ghf, ctx, torch = env
+    n = (mib << 20) + 4096 * 3 + 77
+    rows = ghf.chunk_symbols(n) // 4096
+    assert rows == {117: 5, 130: 6, 146: 7, 200: 9, 230: 10}[mib], rows
+    g = torch.Generator(device="cuda")
+    g.manual_seed(mib)
+    d_in = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)
+    d_in[::3] &= 0x1F  # skew: lengths differ
+    hist = ctx.histogram(d_in)
+    ctx.sync()
+    want = torch.bincount(d_in.to(torch.int64), minlength=256)
+    assert bool((hist[:256] == want).all().item()) and int(hist[256].item()) == 1
+    code = ctx.build_code(hist)
+    total = ctx.encode_plan(d_in, code)
+    ctx.sync()
+    lengths = torch.tensor(list(ctx.code_to_host(code).length)[:256], dtype=torch.int64, device="cuda")
+    assert int(total.item()) == int((want * lengths).sum().item())
