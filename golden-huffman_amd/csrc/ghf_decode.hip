@@ -1018,6 +1018,7 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint
     const uint32_t hi = lo + kSubBits < limit ? lo + kSubBits : limit;  // (behind the stream's end nothing is decoded)
     uint8_t* const row = tab + sub * stride;
     constexpr uint32_t NC = 5;  // chains in flight per lane
+    const uint32_t nfree = limit >= 64u * kSubBits ? ((uint32_t)kSubBits - S) / (uint32_t)max_len : 0u;  // (wave-uniform: every lane's subsequence is whole)
     for (uint32_t s0 = 0; s0 < S; s0 += NC) {
       K6Cursor c[NC];
       uint32_t p[NC];
@@ -1025,7 +1026,13 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint
       for (uint32_t j = 0; j < NC; ++j) {
         p[j] = lo + s0 + j;
         c[j].open(lin, la0, base + p[j]);
-        if (s0 + j >= S) p[j] = hi;  // no such chain
+        if (s0 + j >= S && nfree == 0u) p[j] = hi;  // no such chain (with free steps it simply runs along: never stored)
+      }
+      // the first (512 - S) / max_len steps cannot carry any chain out of its subsequence: no test per step (a chain
+      // slot that stands for no entry offset steps along behind the subsequence -- inside the tile, never stored)
+      for (uint32_t k = 0; k < nfree; ++k) {
+#pragma unroll
+        for (uint32_t j = 0; j < NC; ++j) p[j] += (k6_step<MODE>(c[j], lin, L, T1, lut_bits, max_len, C2) >> 8) & 0xFFu;
       }
       for (;;) {
         bool any = false;
