@@ -188,6 +188,51 @@ def test_foreign_stream_16MiB(env, kind):
     assert np.array_equal(out[:n].cpu().numpy(), data)
 
 
+def _bytes_that_do_not_compress(n, rare, seed):
+    """every byte value equally often, `rare` a little less: 255 codes of 8 bits, 9 bits for `rare` and the end mark"""
+    rng = np.random.default_rng(seed)
+    per = n // 256
+    data = np.repeat(np.arange(256, dtype=np.uint8), per)
+    data = data[np.logical_or(data != rare, np.arange(data.size) % 8 != 0)]  # `rare`: 7/8 of the others' count
+    return rng.permutation(data)
+
+
+@pytest.mark.parametrize("case", ["shuffled", "sorted", "rare_in_runs", "rare_255", "bytes_behind_the_end_mark", "one_group", "eight_subsequences"])
+def test_foreign_stream_of_8_and_9_bit_codes(env, case):
+    """K6's byte classes (k_sync_table / k_fn_apply / k_sync_index on class masks instead of symbol steps): runs of 9-bit
+    codes (more than a row counts: the confirming pass takes those subsequences), either value as the rare one, a stream
+    with bytes behind its end mark (the first end mark ends it, as in the reference's decoder), streams too short for a
+    whole group of 64 subsequences."""
+    ghf, ctx, torch = env
+    n = {"one_group": 5000, "eight_subsequences": 511}.get(case, (3 << 20) + 12345)
+    rare = 255 if case == "rare_255" else (0 if case == "sorted" else 77)
+    if n == 511:  # every value twice, `rare` once
+        data = np.random.default_rng(3).permutation(np.delete(np.repeat(np.arange(256, dtype=np.uint8), 2), 2 * rare))
+    else:
+        data = _bytes_that_do_not_compress(n, rare, seed=n % 1000)
+    if case == "sorted":
+        data = np.sort(data)
+    if case == "rare_in_runs":
+        data = data.copy()
+        data[1000:1400] = rare
+        data[200000:200090] = rare
+        keep = np.flatnonzero(data == rare)
+        # (still the least frequent value: take as many of them away elsewhere)
+        drop = keep[keep >= 300000][:480]
+        data = np.delete(data, drop)
+    crs = orc.compress(data)
+    code, hs = ghf.parse_header(crs)
+    assert (code.min_len, code.max_len) == (8, 9)
+    stream = crs
+    if case == "bytes_behind_the_end_mark":
+        stream = np.concatenate([crs, np.random.default_rng(5).integers(0, 256, 100000, dtype=np.uint8)])
+    d_stream = to_dev(torch, np.concatenate([stream, np.zeros(64, np.uint8)]))
+    out, nout = ctx.decode(d_stream, stream.size, ctx.code_to_device(code), None, cap=data.size + 4096)
+    ctx.sync()
+    assert int(nout.item()) == data.size
+    assert np.array_equal(out[: data.size].cpu().numpy(), data)
+
+
 def test_foreign_stream_truncated_is_reported(env):
     ghf, ctx, torch = env
     data = dg.zipf_bytes(100000, seed=4)
