@@ -821,6 +821,7 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
       index->n_chunks != (index->n_symbols + kBlockSymbols - 1) / kBlockSymbols)
     return fail(c, GHF_E_INVAL, "ghf_decode: malformed index");
   if (cap < index->n_symbols) return fail(c, GHF_E_CAP, "ghf_decode: output capacity below n_symbols");
+  if (index->n_chunks >= kDecMaxGroups) return fail(c, GHF_E_INVAL, "ghf_decode: more than 2^44 symbols in one call");
   DecParams p;
   p.stream = d_stream;
   p.stream_bytes = stream_bytes;
@@ -1023,6 +1024,7 @@ int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int
       index->n_chunks != (index->n_symbols + kBlockSymbols - 1) / kBlockSymbols)
     return fail(c, GHF_E_INVAL, "ghf_crs_decode: malformed index");
   if (cap < index->n_symbols) return fail(c, GHF_E_CAP, "ghf_crs_decode: output capacity below n_symbols");
+  if (index->n_chunks >= kDecMaxGroups) return fail(c, GHF_E_INVAL, "ghf_crs_decode: more than 2^44 symbols in one call");
   DecParams p;
   p.stream = d_stream;
   p.stream_bytes = stream_bytes;

@@ -568,7 +568,10 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
   }
   if (blockIdx.x == 0 && tid == 0 && P.out_bytes) *P.out_bytes = P.n_symbols;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar loop control
-  const uint64_t ngroups = (P.n_segs + 63) >> 6;
+  // (group numbers are 32-bit -- launch_decode refuses more -- so that the loop control is scalar compares of single
+  //  registers: gfx9 has no scalar 64-bit ordering compare, and a uniform 64-bit bound kept in a VGPR pair was the one value
+  //  the allocator spilled inside the hot loops)
+  const uint32_t ngroups = (uint32_t)((P.n_segs + 63) >> 6);
   const uint64_t full_bytes = P.stream_bytes & ~15ull;  // whole 16-byte vectors of the stream
   const bool out_aligned = (((uintptr_t)P.out) & 15u) == 0;
   const uint8_t* const lin = L.in;
@@ -586,15 +589,16 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
   };
   // every wave's first three groups are fixed (no round trip to a counter before the first load can be issued: three
   // dependent atomics on 16 counters cost the 4096 waves several microseconds of start-up); tickets number the rest
-  const uint64_t nwaves = (uint64_t)gridDim.x * kDec7Waves;
-  const uint64_t wid = (uint64_t)blockIdx.x * kDec7Waves + (uint64_t)wave;
-  auto ticket_group = [&](unsigned int t) -> uint64_t {
-    return 3 * nwaves + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * ncls + cls;
+  const uint32_t nwaves = gridDim.x * kDec7Waves;
+  const uint32_t wid = blockIdx.x * kDec7Waves + (uint32_t)wave;
+  auto ticket_group = [&](unsigned int t) -> uint32_t {  // (saturating: a number past the end stays past the end)
+    const uint64_t g = 3ull * nwaves + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * ncls + cls;
+    return g < 0xFFFFFFFFull ? (uint32_t)g : 0xFFFFFFFFu;
   };
-  uint64_t group = wid;
-  uint64_t g1 = wid + nwaves, g2 = wid + 2 * nwaves;  // this wave's next two groups
-  const uint64_t glast = ngroups - 1;
-  auto clampg = [&](uint64_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
+  uint32_t group = wid;
+  uint32_t g1 = wid + nwaves, g2 = wid + 2 * nwaves;  // this wave's next two groups
+  const uint32_t glast = ngroups - 1;
+  auto clampg = [&](uint32_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
 
   // vector k of a lane = bytes byte0 + k*1024 + lane*16 .. of the stream; it is loaded when it begins inside the span
   // and ends inside the stream's whole 16-byte vectors
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
       dec_issue_meta(P, clampg(g2), ln, M);
       const unsigned int t3 = ticket_issue();  // resolved after the decode
       // ---- 2. decode
-      const uint64_t seg0 = group * 64;
+      const uint64_t seg0 = (uint64_t)group * 64;
       const uint64_t seg = seg0 + ln;
       const uint64_t sym0 = seg * kSegSymbols;
       if (HOT) {
@@ -769,6 +773,7 @@ void launch_decode(const DecParams& p, hipStream_t s) {
   const uint64_t groups = (p.n_segs + 63) / 64;
   uint64_t blocks = (groups + kDec7Waves - 1) / kDec7Waves;
   if (blocks == 0) return;
+  if (groups >= kDecMaxGroups) return;  // (k_decode numbers its groups in 32 bits; the callers refuse such an index first)
   if (blocks > 256) blocks = 256;  // persistent: one workgroup of 16 waves per CU (its LDS tiles + table take 146 KiB)
   hipLaunchKernelGGL(k_decode, dim3((uint32_t)blocks), dim3(kDec7Threads), 0, s, p);
 }

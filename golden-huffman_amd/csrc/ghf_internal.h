@@ -145,6 +145,7 @@ void launch_plan(const uint8_t* d_in, uint64_t n, uint32_t chunk, uint32_t nchun
 void launch_scan(uint64_t* d_v, uint32_t count, uint64_t* d_total, hipStream_t s);
 void launch_emit(const EmitParams& p, hipStream_t s);
 void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_status, hipStream_t s);
+constexpr uint64_t kDecMaxGroups = 0xFFFF0000ull;  // groups of 4096 symbols one k_decode launch takes (2^44 symbols)
 void launch_decode(const DecParams& p, hipStream_t s);
 void launch_crs_build_code(const uint64_t* d_hist, ghf_tree* d_tree, ghf_code* d_code, uint64_t* d_start_bit, int* d_status,
                            hipStream_t s);

@@ -979,7 +979,9 @@ class PieceDecoder {
     // a pool thread makes 97 % of the estimated pages, and it leaves in one sweep at the end, when the exact size is known
     // (sweeping the pieces whose pages exist while the rest is still being made was tried: page-making and copying
     // into the same file get in each other's way, 4 GiB took 480-700 ms instead of 410-470).
-    // Otherwise (or once `whole_` is full) a piece leaves as soon as it is decoded, through the kOut-deep ring.
+    // Otherwise (or once `whole_` is full) a piece leaves as soon as it is decoded, through the kOut-deep ring -- also when
+    // the output file is written over (GHF_SINK=reuse: its pages exist, so the copies out overlap the copies in; 4 GiB
+    // uniform 191 instead of 236 ms, profiles/r03/pipe_trace_reuse_uniform*.log).
     struct Held {
       const uint8_t* d;
       size_t bytes, at;
@@ -1009,7 +1011,7 @@ class PieceDecoder {
         sync(d_in_[r].u8(), pipe().padded(k), first, end_bit, &landing, &nsym, &has_end);  // K6; the call waits for its own result
       }
       if (nsym > out_cap) throw Error(GHF_E_CORRUPT, "a piece decodes to more than 8 symbols per byte");
-      if (k == 0 && np > 2 && !has_end && Pipe::wants_map(8 * body)) {
+      if (k == 0 && np > 2 && !has_end && Pipe::wants_map(8 * body) && !detail::sink_reuses()) {
         const double est = (double)nsym / (double)pipe().own(0) * (double)(body + tail_n);
         const size_t want = (size_t)(est * 1.05) + 4 * out_cap;
         if (want <= env_bytes("GHF_RESIDENT_BYTES", (size_t)64 << 30)) {

@@ -16,13 +16,15 @@ build() {  # name, sed for ghf_decode.hip, sed for ghf_emit.hip, sed for ghf_ker
   rm -rf $T
   echo built $1
 }
-# cache-policy variants of the pipelined bench (scratch/bench_with_lib.py)
+# K7: what bounds it?  (scratch/ablate_run.py times k_decode alone.)  These five builds were made from the tree that had the
+# byte-phase decoder in it (VAR 6, profiles/r03/experiments/k7_byte_phases_decoder.hip.txt; logs: k7_ablate_*.log beside it):
+# base = byte phases, k7_generic = the shipped decoder, nodecode / nostore = the memory skeleton.  On the shipped tree only
+# k7_nostore still applies.
 build base "" "" "" &
-build k7_span_plain 's|      R\[k\] = load_stream(base + (o + 16u <= lim ? o : 0u));|      R[k] = *reinterpret_cast<const uint4*>(base + (o + 16u <= lim ? o : 0u));|' "" "" &
-build k7_store_plain 's|            store_stream(og + r \* 1024, \*reinterpret_cast<const uint4\*>(tile + sl \* 16 + piece \* 4));|            *reinterpret_cast<uint4*>(og + r * 1024) = *reinterpret_cast<const uint4*>(tile + sl * 16 + piece * 4);|' "" "" &
+build k7_generic 's|  const bool byte_code = P.dt->kind == 0|  const bool byte_code = false \&\& P.dt->kind == 0|' "" "" &
+build k7_nodecode 's|          else if (VAR == 6) acc = dec_hot_bytes(lin, la0, T1, thr8, cur.pos, out, used);|          else if (VAR == 6) { for (int d = 0; d < 16; ++d) out[d] = cur.pos + d; used = cur.expect; acc = 0; }|' "" "" &
 wait
-build k5_store_nt "" 's|      W.out_units\[W.unit_base + j\] = v;|      store_stream(\&W.out_units[W.unit_base + j], v);|' "" &
-build k1_load_plain "" "" 's|load_stream(vptr(|*(vptr(|g' &
-build k5_load_nt "" 's|            buf\[j\] = pv\[nx \* 64\];|            buf[j] = load_stream(pv + nx * 64);|' "" &
+build k7_nostore 's|            store_stream(og + r \* 1024, \*reinterpret_cast<const uint4\*>(tile + sl \* 16 + piece \* 4));|            if (P.n_symbols == 1) store_stream(og + r * 1024, *reinterpret_cast<const uint4*>(tile + sl * 16 + piece * 4));|' "" "" &
+build k7_nodecode_nostore 's|          else if (VAR == 6) acc = dec_hot_bytes(lin, la0, T1, thr8, cur.pos, out, used);|          else if (VAR == 6) { for (int d = 0; d < 16; ++d) out[d] = cur.pos + d; used = cur.expect; acc = 0; }|;s|            store_stream(og + r \* 1024, \*reinterpret_cast<const uint4\*>(tile + sl \* 16 + piece \* 4));|            if (P.n_symbols == 1) store_stream(og + r * 1024, *reinterpret_cast<const uint4*>(tile + sl * 16 + piece * 4));|' "" "" &
 wait
 ls $R/scratch/exp/

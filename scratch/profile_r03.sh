@@ -23,11 +23,21 @@ for MIB in 256 4096; do
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $O/pmc${MIB}_p$i -- python3 $R/bench.py --mib $MIB --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-configs > $O/pmc${MIB}_p$i.log 2>&1 || echo "pmc $MIB pass $i failed"
   done
 done
+echo "== side-car-less decode (K6 + K7), per kernel"
+for KIND in uniform zipf sym16; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/foreign_$KIND -- python3 $R/scratch/foreign_prof.py $KIND > $O/foreign_$KIND.log 2>&1 || echo "foreign $KIND failed"
+done
 cd $R
+echo "== the other 256 MiB inputs"
+for KIND in zipf sym16; do
+  python3 bench.py --steps 100 --kind $KIND --no-configs --no-cpu-baseline > $O/bench_256MiB_$KIND.json 2> /dev/null
+done
 echo "== memory microbenchmark"
 timeout -k 10 300 ./scratch/membench > $O/membench.txt 2>&1
 echo "== file to file"
 timeout -k 10 600 python3 scratch/file_perf.py 4 uniform zipf > $O/file_perf.log 2>&1; cp gpurun_out/file_perf.json $O/file_perf.json
+timeout -k 10 300 python3 scratch/file_trace_reuse.py uniform > $O/pipe_trace_reuse_uniform.log 2>&1
+timeout -k 10 300 python3 scratch/file_trace_reuse.py zipf > $O/pipe_trace_reuse_zipf.log 2>&1
 # raw per-dispatch traces are large; keep stats and counter files only
 find $O -name '*kernel_trace.csv' -size +1M -delete
 find $O -name '*.db' -delete

@@ -233,6 +233,47 @@ def test_foreign_stream_of_8_and_9_bit_codes(env, case):
     assert np.array_equal(out[: data.size].cpu().numpy(), data)
 
 
+@pytest.mark.parametrize("case", ["shuffled", "sorted", "rare_in_runs", "nine_in_one_segment"])
+def test_codes_of_8_and_9_bits_with_runs_of_the_rare_value(env, case):
+    """bytes that do not compress (255 codes of 8 bits, two of 9) with the 9-bit byte value alone, in runs, eight and nine
+    times in one 64-symbol segment: K5's bytes equal the oracle's, K7 reads them back (written for the byte-phase decoder
+    experiment of round 3, profiles/r03/experiments/k7_byte_phases_decoder.hip.txt; kept for the generic decoder)."""
+    ghf, ctx, torch = env
+    n = (2 << 20) + 4321
+    data = _bytes_that_do_not_compress(n, 200, seed=9)
+    if case == "sorted":
+        data = np.sort(data)
+    elif case == "rare_in_runs":
+        data = data.copy()
+        idx = np.flatnonzero(data == 200)
+        data[5000:5300] = 200
+        data[700000:700008] = 200   # exactly eight in one segment: still the fast way
+        data[900000:900009] = 200   # nine
+        data = np.delete(data, idx[idx > 1000000][:320])
+    elif case == "nine_in_one_segment":
+        data = data.copy()
+        idx = np.flatnonzero(data == 200)
+        data[64 * 1000: 64 * 1000 + 9] = 200
+        data = np.delete(data, idx[idx > 1000000][:9])
+    ref = orc.compress(data)
+    code, _ = ghf.parse_header(ref)
+    assert (code.min_len, code.max_len) == (8, 9)
+    d_in, d_out, nb, d_code, idx = run_compress(ghf, ctx, torch, data)
+    assert nb == ref.size and np.array_equal(d_out[:nb].cpu().numpy(), ref)
+    back, nout = ctx.decode(d_out, nb, d_code, idx)
+    ctx.sync()
+    assert int(nout.item()) == data.size and np.array_equal(back[: data.size].cpu().numpy(), data)
+    # a flipped bit inside a segment is caught by the segment-end check (or decodes to the wrong bytes and is caught there)
+    bad = d_out.clone()
+    bad[4000] ^= 0x10
+    ctx.decode(bad, nb, d_code, idx)
+    try:
+        ctx.sync()  # (a flip that maps an 8-bit code onto an 8-bit code keeps every length: nothing to detect)
+    except ghf.GhfError as e:
+        assert e.status == 7
+    ctx.index_free(idx)
+
+
 def test_foreign_stream_truncated_is_reported(env):
     ghf, ctx, torch = env
     data = dg.zipf_bytes(100000, seed=4)
