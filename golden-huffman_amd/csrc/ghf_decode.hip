@@ -413,27 +413,31 @@ __device__ __forceinline__ uint32_t dec_hot_pair(const uint8_t* lin, uint32_t la
   return acc;
 }
 
-// HOT for codes beyond the direct table (max_len > 12; no BASELINE config): the reference's linear extension on a miss,
-// four output bytes per store, straight to HBM.
+// HOT for codes beyond the direct table (max_len > 12: Zipf 1.1 over 256 values has 13..14-bit codes for its rarest ones
+// and the end mark): the reference's linear extension on a miss, sixteen output bytes per store, straight to memory (the
+// callers' out is 16-byte aligned on this path).
 template <int K>
 __device__ __forceinline__ uint32_t dec_hot_long(const DecLds7& L, const uint8_t* lin, uint32_t la0, const DecLut& T, int lut_bits, int max_len,
                                                  uint32_t pos, uint8_t* optr, uint32_t& used) {
   GHF_WINDOW_OPEN();
   uint32_t acc = 0;
 #pragma unroll 1
-  for (int d = 0; d < 16; ++d) {
-    uint32_t w = 0;
+  for (int q = 0; q < 4; ++q) {  // sixteen symbols = one 16-byte store (a quarter of the store instructions of one dword each)
+    uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j % K == 0) GHF_REFILL();
-      const uint32_t v = (uint32_t)((W << o) >> 32);
-      uint32_t ent = dec_lookup(T, v);
-      if (__builtin_expect((ent & kEntNone) != 0, 0)) ent = dec_long_entry(L, v, lut_bits, max_len);
-      o += (ent >> 8) & 0xFFu;
-      acc |= ent;
-      w |= (ent & 0xFFu) << (8 * j);
+    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j % K == 0) GHF_REFILL();
+        const uint32_t v = (uint32_t)((W << o) >> 32);
+        uint32_t ent = dec_lookup(T, v);
+        if (__builtin_expect((ent & kEntNone) != 0, 0)) ent = dec_long_entry(L, v, lut_bits, max_len);
+        o += (ent >> 8) & 0xFFu;
+        acc |= ent;
+        w[d] |= (ent & 0xFFu) << (8 * j);
+      }
     }
-    reinterpret_cast<uint32_t*>(optr)[d] = w;
+    reinterpret_cast<uint4*>(optr)[q] = make_uint4(w[0], w[1], w[2], w[3]);
   }
   used = GHF_WINDOW_USED();
   return acc;
