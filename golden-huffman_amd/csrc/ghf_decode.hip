@@ -1233,7 +1233,7 @@ template <typename OutT>
 __global__ __launch_bounds__(64) void k_fn_apply(const uint8_t* __restrict__ f, uint64_t n, uint32_t stride,
                                                  const uint8_t* __restrict__ tile_start, uint32_t entry, OutT* __restrict__ start,
                                                  const uint32_t* __restrict__ byte_flag, uint64_t n_settle, uint32_t* __restrict__ cnt_out,
-                                                 uint16_t* __restrict__ used_out) {
+                                                 uint16_t* __restrict__ used_out, uint8_t* __restrict__ eof_out) {
   __shared__ __attribute__((aligned(16))) uint8_t fl[64 * 64];
   __shared__ uint8_t st[64];
   const uint64_t t = blockIdx.x;
@@ -1260,6 +1260,7 @@ __global__ __launch_bounds__(64) void k_fn_apply(const uint8_t* __restrict__ f, 
     if (e <= 8u && n9 != 7u && !eofs) {  // bits from the entry offset to the landing bit = 8 per code + 1 per 9-bit code
       cnt_out[first + lane] = ((uint32_t)kSubBits + row[e] - e - n9) >> 3;
       used_out[first + lane] = (uint16_t)e;
+      eof_out[first + lane] = 0;  // (a pass that ran on an earlier guess may have seen a fake end mark here)
     }
   }
 }
@@ -1310,16 +1311,16 @@ void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride, uint32_
   }
   const uint32_t* const no_flag = nullptr;
   hipLaunchKernelGGL(k_fn_apply<uint8_t>, dim3(1), dim3(64), 0, s, fn[levels - 1], cnt[levels - 1], stride, (const uint8_t*)nullptr,
-                     entry, st[levels - 1], no_flag, 0ull, (uint32_t*)nullptr, (uint16_t*)nullptr);
+                     entry, st[levels - 1], no_flag, 0ull, (uint32_t*)nullptr, (uint16_t*)nullptr, (uint8_t*)nullptr);
   for (int l = levels - 2; l >= 1; --l)
     hipLaunchKernelGGL(k_fn_apply<uint8_t>, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], stride, st[l + 1], 0u, st[l], no_flag,
-                       0ull, (uint32_t*)nullptr, (uint16_t*)nullptr);
+                       0ull, (uint32_t*)nullptr, (uint16_t*)nullptr, (uint8_t*)nullptr);
   // settled by the lowest level (byte classes only): whole groups of 64 subsequences, and never the last subsequence (its
   // landing bit, the end of a piece and the end mark are k_sync_pass's)
   uint64_t n_settle = (p.end_bit - p.body_bit0) / (64ull * kSubBits) * 64ull;
   if (n_settle > p.nsub - 1) n_settle = p.nsub - 1;
   hipLaunchKernelGGL(k_fn_apply<uint16_t>, dim3((uint32_t)cnt[1]), dim3(64), 0, s, fn[0], cnt[0], stride, st[1], 0u, p.start,
-                     (const uint32_t*)byte_flag, (unsigned long long)n_settle, p.cnt, p.used);
+                     (const uint32_t*)byte_flag, (unsigned long long)n_settle, p.cnt, p.used, p.eof);
 }
 
 // first subsequence that holds the end mark (valid once the passes have converged)
