@@ -941,34 +941,38 @@ __device__ __forceinline__ uint32_t k6_limit(uint64_t body_bits, uint64_t g) {  
   return l > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)l;
 }
 
-// ---- byte classes: K6 on the canonical code of bytes that do not compress --------------------------------------------
-// 256 byte values + the end mark, none of them rare enough for a 10-bit code: 255 codes of 8 bits and two of 9 (the least
-// frequent byte value and the end mark: 9-bit codes 0 and 1, every 8-bit code >= 0x01).  A decoder that stands at bit p
-// moves to p + 8, or to p + 9 when the eight bits at p are zero.  So it walks along the positions of its CLASS p mod 8 until
-// it meets eight zero bits, and then along the next class: per subsequence a handful of jumps instead of 57 steps (and nine
-// chains of them in k_sync_table: this code is the one that re-synchronises slowest).  The 64 positions of class r are one
-// 64-bit mask F[r] (bit 63 - i: the byte-wide window at bit 8 i + r is zero), computed for all eight classes at once from
-// the bit planes of the subsequence's 64 bytes (8 x 8 bit-matrix transposes: no step touches a single symbol); G[r] marks
-// those of them whose ninth bit makes the code the end mark.
-struct K6Byte {
-  bool on;           // the code is of that kind (wave-uniform)
-  uint32_t eof_bit;  // last bit of the end mark's 9-bit code
+// ---- classes: K6 on canonical codes of L and L + 1 bits, L = 8 or 4 ---------------------------------------------------
+// Bytes that do not compress -- 256 byte values + the end mark, none of them rare enough for a 10-bit code: 255 codes of 8
+// bits and two of 9 (the least frequent value and the end mark: 9-bit codes 0 and 1, every 8-bit code >= 0x01) -- and the
+// same shape one size down, 16 equally likely values + the end mark: 15 codes of 4 bits, two of 5.  A decoder that stands at
+// bit p moves to p + L, or to p + L + 1 when the L bits at p are zero.  So it walks along the positions of its CLASS p mod 8
+// (L = 4: of the two classes p mod 8 and p + 4 mod 8, alternately) until it meets L zero bits, and then along the next
+// class: per subsequence a handful of jumps instead of 57 (128) steps -- and max_len chains of them in k_sync_table: these
+// codes are the ones that re-synchronise slowest.  The 64 positions of class r are one 64-bit mask F[r] (bit 63 - i: the
+// L bits at bit 8 i + r are zero), computed for all eight classes at once from the bit planes of the subsequence's 64 bytes
+// (8 x 8 bit-matrix transposes: no step touches a single symbol); G[r] marks those of them whose next bit makes the code
+// the end mark.
+struct K6Cls {
+  int L;             // 8 or 4: the code is of that kind (wave-uniform); 0: it is not
+  uint32_t eof_bit;  // last bit of the end mark's code
 };
-__device__ __forceinline__ K6Byte k6_byte(int k6_mode, int min_len, int max_len, const K6Two& C2, uint64_t body_bit0) {
-  K6Byte B;
+__device__ __forceinline__ K6Cls k6_cls(int k6_mode, int min_len, int max_len, const K6Two& C2, uint64_t body_bit0) {
+  K6Cls B;
   // (a body begins on a 4-byte boundary of a 16-byte aligned buffer: behind a .crs2 header, or at byte 0 of a piece)
-  B.on = k6_mode == 2 && min_len == 8 && max_len == 9 && C2.thr == (1u << 24) && C2.eof_span == (1u << 23) && C2.eof_lo < (1u << 24) &&
-         (body_bit0 & 31u) == 0;
-  B.eof_bit = (C2.eof_lo >> 23) & 1u;
+  const bool shape = k6_mode == 2 && max_len == min_len + 1 && (min_len == 8 || min_len == 4) && C2.thr == (1u << (32 - min_len)) &&
+                     C2.eof_span == (1u << (31 - min_len)) && C2.eof_lo < C2.thr && (body_bit0 & 31u) == 0;
+  B.L = shape ? min_len : 0;
+  B.eof_bit = (C2.eof_lo >> ((31 - min_len) & 31)) & 1u;
   return B;
 }
 __device__ __forceinline__ uint32_t bfi32(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }  // v_bfi_b32
 // exchange the bits under m with the bits under m << d
 __device__ __forceinline__ uint32_t delta_swap32(uint32_t x, uint32_t m, int d) { return bfi32(m, x >> d, bfi32(m << d, x << d, x)); }
 
-// F (and G) of the subsequence that begins at bit `bitpos` (a multiple of 32: K6Byte::on) of the wave's staged tile
-template <bool WITH_EOF>
+// F (and G) of the subsequence that begins at bit `bitpos` (a multiple of 32: k6_cls) of the wave's staged tile
+template <int L, bool WITH_EOF>
 __device__ __forceinline__ void k6_classes(const uint8_t* lin, uint32_t la0, uint32_t bitpos, uint32_t eof_bit, uint64_t (&F)[8], uint64_t (&G)[8]) {
+  static_assert(L == 8 || L == 4, "class length");
   const uint32_t la = la0 + ((bitpos >> 5) << 2);
   uint32_t E[17];  // the subsequence's 512 bits + 32 of look-ahead, first bit in bit 31 of E[0]
 #pragma unroll
@@ -984,6 +988,7 @@ __device__ __forceinline__ void k6_classes(const uint8_t* lin, uint32_t la0, uin
     T[g][1] = bfi32(0xF0F0F0F0u, hi << 4, lo);
   }
   // plane s of all 64 bytes: Q[s][0] = bytes 0..31, Q[s][1] = bytes 32..63 (byte i in bit 31 - i mod 32)
+  constexpr int NQ = 8 + L + (WITH_EOF ? 0 : -1);  // planes 0 .. 7 + L (7 + L - 1 without the end-mark masks)
   uint32_t Q[16][2];
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -998,10 +1003,9 @@ __device__ __forceinline__ void k6_classes(const uint8_t* lin, uint32_t la0, uin
       Q[4 * half + 3][hh] = __builtin_amdgcn_perm(aby, cdy, 0x05040100u);
     }
   }
-  // planes 8..15: the same bits one byte later (bit s of bytes 1..64)
+  // planes 8..: the same bits one byte later (bit s of bytes 1..64)
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    if (s == 7 && !WITH_EOF) break;
+  for (int s = 0; s + 8 < NQ; ++s) {
     Q[s + 8][0] = alignbit(Q[s][0], Q[s][1], 31);
     Q[s + 8][1] = (Q[s][1] << 1) | ((E[16] >> (31 - s)) & 1u);
   }
@@ -1010,10 +1014,13 @@ __device__ __forceinline__ void k6_classes(const uint8_t* lin, uint32_t la0, uin
   for (int r = 0; r < 8; ++r) {
     uint32_t f[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      f[h] = ~(Q[r][h] | Q[r + 1][h] | Q[r + 2][h] | Q[r + 3][h] | Q[r + 4][h] | Q[r + 5][h] | Q[r + 6][h] | Q[r + 7][h]);
+    for (int h = 0; h < 2; ++h) {
+      uint32_t any = Q[r][h] | Q[r + 1][h] | Q[r + 2][h] | Q[r + 3][h];
+      if (L == 8) any |= Q[r + 4][h] | Q[r + 5][h] | Q[r + 6][h] | Q[r + 7][h];
+      f[h] = ~any;
+    }
     F[r] = ((uint64_t)f[0] << 32) | f[1];
-    if (WITH_EOF) G[r] = ((uint64_t)(f[0] & (Q[r + 8][0] ^ eofx)) << 32) | (f[1] & (Q[r + 8][1] ^ eofx));
+    if (WITH_EOF) G[r] = ((uint64_t)(f[0] & (Q[r + L][0] ^ eofx)) << 32) | (f[1] & (Q[r + L][1] ^ eofx));
   }
 }
 // where the masks of a wave's 64 subsequences live while its chains walk: F in the (unused) table area, [class][thread];
@@ -1024,6 +1031,37 @@ __device__ __forceinline__ uint64_t* k6_g_slot(DecLds7& L, int wave, int lane) {
 }
 static_assert(sizeof(DecLds7::lut) >= 8 * kDec7Threads * sizeof(uint64_t) && kDec7TilePhys >= 8 * 64 * (int)sizeof(uint64_t) && kDec7TilePhys % 8 == 0,
               "room for the class masks");
+// One jump of a chain that stands at bit p < 512 of its subsequence: s = the L-bit codes in front of the next (L + 1)-bit
+// code (found), or in front of the subsequence's end; eof = that code is the end mark.  fmask(c) / gmask(c) = the F / G mask
+// of class c (from LDS; from registers when p is a compile-time constant).  All mask reads are issued together: a jump is
+// ONE LDS round trip.
+template <int L, bool WITH_G, typename FM, typename GM>
+__device__ __forceinline__ uint32_t k6_jump(FM fmask, GM gmask, uint32_t p, bool& found, bool& eof) {
+  const uint32_t a = p & 7u, i = p >> 3;
+  if (L == 8) {
+    const uint64_t m = fmask(a) << i;
+    const uint64_t g = WITH_G ? gmask(a) << i : 0ull;
+    found = m != 0;
+    const uint32_t z = (uint32_t)__builtin_clzll(m | 1ull);
+    eof = WITH_G && found && ((g << z) >> 63);
+    return found ? z : 64u - i;
+  }
+  // L = 4: the chain alternates between class a (steps 0, 2, ..) and class a + 4 mod 8 (steps 1, 3, ..: the same byte when
+  // a < 4, the next one otherwise)
+  const uint32_t b = (a + 4u) & 7u, ib = i + (a >> 2), ibm = ib & 63u;
+  const uint64_t ma = fmask(a) << i;
+  const uint64_t mb = ib < 64u ? fmask(b) << ibm : 0ull;
+  const uint64_t ga = WITH_G ? gmask(a) << i : 0ull;
+  const uint64_t gb = WITH_G ? gmask(b) << ibm : 0ull;
+  const uint32_t ta = (uint32_t)__builtin_clzll(ma | 1ull), tb = (uint32_t)__builtin_clzll(mb | 1ull);
+  const uint32_t sa = ma ? 2u * ta : 1000u;
+  const uint32_t sb = mb ? 2u * tb + 1u : 1000u;
+  const bool first_a = sa < sb;
+  const uint32_t s = first_a ? sa : sb;
+  found = s < 1000u;
+  eof = WITH_G && found && (((first_a ? ga << ta : gb << tb) >> 63) != 0);
+  return found ? s : (515u - p) >> 2;
+}
 
 __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
   GHF_K6_PROLOGUE();
@@ -1096,17 +1134,18 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
 // k_sync_table: lane = subsequence, its max_len chains five at a time -- independent shift -> lookup -> add
 // dependency chains per lane hide the LDS round trip that a single chain leaves exposed (four waves per SIMD do not).
 //
-// Byte classes (k6_classes): the nine chains of a subsequence are walks over the class masks -- per chain and round one
-// LDS read of the mask of its class, a shift, a count of leading zeros.  The row then also says, for every entry offset, how
-// many 9-bit codes the chain met (3 bits, 7 = "seven or more") and whether one of them was the end mark: with the entry
-// offset that the scan arrives at, that IS the subsequence's symbol count -- the lowest k_fn_apply settles every
+// Classes (k6_classes, codes of L and L + 1 bits): the max_len chains of a subsequence are walks over the class masks -- per
+// chain and round one or two LDS reads of the masks of its class, a shift, a count of leading zeros.  The row then also
+// says, for every entry offset, how many (L + 1)-bit codes the chain met and whether one of them was the end mark: with the
+// entry offset that the scan arrives at, that IS the subsequence's symbol count -- the lowest k_fn_apply settles every
 // subsequence whose true chain met no end mark, and the confirming pass has only the others left.
-//   row: bytes 0..8 landing offsets | bytes 10..11 end-mark bits | bytes 12..15 nine 3-bit counts
-__global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint32_t stride, uint8_t* __restrict__ tab, uint32_t* __restrict__ byte_flag) {
+//   row, L = 8: bytes 0..8 landing offsets | 10..11 end-mark bits | 12..15 nine 3-bit counts (7 = seven or more)
+//   row, L = 4: bytes 0..4 landing offsets | 5..9 five 8-bit counts (255 = or more) | 10..11 end-mark bits
+__global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint32_t stride, uint8_t* __restrict__ tab, uint32_t* __restrict__ cls_flag) {
   GHF_K6_PROLOGUE();
   const uint32_t S = (uint32_t)max_len < stride ? (uint32_t)max_len : stride;
-  const K6Byte BY = k6_byte(k6_mode, P.dt->min_len, max_len, C2, P.body_bit0);
-  if (blockIdx.x == 0 && tid == 0) *byte_flag = BY.on ? 1u : 0u;
+  const K6Cls CL = k6_cls(k6_mode, P.dt->min_len, max_len, C2, P.body_bit0);
+  if (blockIdx.x == 0 && tid == 0) *cls_flag = (uint32_t)CL.L;
   auto run = [&](auto mode_tag) {
   constexpr int MODE = decltype(mode_tag)::value;
   for (uint64_t g = (uint64_t)blockIdx.x * kK6Waves + wave; g < ngroups; g += (uint64_t)gridDim.x * kK6Waves) {
@@ -1117,52 +1156,71 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint
     if (sub >= P.nsub) continue;
     const uint32_t limit = k6_limit(body_bits, g);
     const uint32_t lo = (uint32_t)lane * kSubBits;
-    if (MODE == 2 && BY.on && limit >= 64u * kSubBits) {  // (wave-uniform: every lane's subsequence is whole)
-      uint64_t F[8], G[8];
-      k6_classes<true>(lin, la0, base + lo, BY.eof_bit, F, G);
-      wave_sync();  // (every lane has its bytes: the tile may take the G masks)
-      uint64_t* const Fl = k6_f_slot(L, tid);
-      uint64_t* const Gl = k6_g_slot(L, wave, lane);
+    if (MODE == 2 && CL.L && limit >= 64u * kSubBits) {  // (wave-uniform: every lane's subsequence is whole)
+      auto walk = [&](auto l_tag) {
+        constexpr int CLEN = decltype(l_tag)::value, NCH = CLEN + 1;  // the chains: entry offsets 0 .. L
+        uint64_t F[8], G[8];
+        k6_classes<CLEN, true>(lin, la0, base + lo, CL.eof_bit, F, G);
+        wave_sync();  // (every lane has its bytes: the tile may take the G masks)
+        uint64_t* const Fl = k6_f_slot(L, tid);
+        uint64_t* const Gl = k6_g_slot(L, wave, lane);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        Fl[r * kK6Threads] = F[r];
-        Gl[r * 64] = G[r];
-      }
-      // a chain = the bit p at which its next code begins (class p & 7, index p >> 3); >= 512: it has left the subsequence
-      uint32_t p[9], n9[9], eofs = 0;
-      bool any = false;
+        for (int r = 0; r < 8; ++r) {
+          Fl[r * kK6Threads] = F[r];
+          Gl[r * 64] = G[r];
+        }
+        // a chain = the bit p at which its next code begins; >= 512: it has left the subsequence
+        uint32_t p[NCH], nl[NCH], eofs = 0;
+        bool any = false;
 #pragma unroll
-      for (int e = 0; e < 9; ++e) {  // first round: the classes are the entry offsets, the masks still in registers
-        const uint64_t m = e < 8 ? F[e] : F[0] << 1, gm = e < 8 ? G[e] : G[0] << 1;
-        const bool found = m != 0;
-        const uint32_t z = (uint32_t)__builtin_clzll(m | 1ull);
-        p[e] = found ? (uint32_t)e + 8u * z + 9u : 512u + ((uint32_t)e & 7u);
-        n9[e] = found ? 1u : 0u;
-        eofs |= (found && ((gm << z) >> 63)) ? (1u << e) : 0u;
-        any |= p[e] < 512u;
-      }
-      while (any) {
-        any = false;
-#pragma unroll
-        for (int e = 0; e < 9; ++e) {
-          const uint32_t pe = p[e], r = pe & 7u, i = (pe >> 3) & 63u;
-          const bool act = pe < 512u;
-          const uint64_t m = Fl[r * kK6Threads] << i, gm = Gl[r * 64] << i;
-          const bool found = act && m != 0;
-          const uint32_t z = (uint32_t)__builtin_clzll(m | 1ull);
-          p[e] = act ? (found ? pe + 8u * z + 9u : (512u | r)) : pe;
-          n9[e] += found ? 1u : 0u;
-          eofs |= (found && ((gm << z) >> 63)) ? (1u << e) : 0u;
+        for (int e = 0; e < NCH; ++e) {  // first round: every chain stands at its entry offset, the masks still in registers
+          bool found, eof;
+          const uint32_t sh = k6_jump<CLEN, true>([&](uint32_t c) { return F[c]; }, [&](uint32_t c) { return G[c]; }, (uint32_t)e, found, eof);
+          const uint32_t q = (uint32_t)e + (uint32_t)CLEN * sh;  // the long code (found), or the first position behind the subsequence
+          p[e] = found ? q + (uint32_t)CLEN + 1u : q;
+          nl[e] = found ? 1u : 0u;
+          eofs |= eof ? (1u << e) : 0u;
           any |= p[e] < 512u;
         }
-      }
-      uint32_t w3 = 0;
+        while (any) {
+          any = false;
 #pragma unroll
-      for (int e = 0; e < 9; ++e) w3 |= (n9[e] < 7u ? n9[e] : 7u) << (3 * e);
-      const uint4 row = make_uint4((p[0] - 512u) | (p[1] - 512u) << 8 | (p[2] - 512u) << 16 | (p[3] - 512u) << 24,
-                                   (p[4] - 512u) | (p[5] - 512u) << 8 | (p[6] - 512u) << 16 | (p[7] - 512u) << 24,
-                                   (p[8] - 512u) | eofs << 16, w3);
-      *reinterpret_cast<uint4*>(tab + sub * stride) = row;
+          for (int e = 0; e < NCH; ++e) {
+            const bool act = p[e] < 512u;
+            const uint32_t pe = act ? p[e] : 0u;
+            bool found, eof;
+            // (L = 8: the long code lies in the chain's own class, its G mask is read WITH the F mask -- one LDS round trip per
+            //  jump.  L = 4: it lies in one of two classes; reading both candidates' G masks up front gave wrong end-mark bits
+            //  in this kernel on the GPU -- not in a stand-alone harness of the same function, scratch/jump_gpu_test.hip, and
+            //  not on the host -- which is not root-caused; the mask of the class the jump arrives in is read behind it.)
+            const uint32_t sh = k6_jump<CLEN, CLEN == 8>([&](uint32_t c) { return Fl[c * kK6Threads]; }, [&](uint32_t c) { return Gl[c * 64]; }, pe, found, eof);
+            const uint32_t q = pe + (uint32_t)CLEN * sh;
+            if (CLEN == 4) eof = found && ((Gl[(q & 7u) * 64] << ((q >> 3) & 63u)) >> 63) != 0;
+            p[e] = act ? (found ? q + (uint32_t)CLEN + 1u : q) : p[e];
+            nl[e] += (act && found) ? 1u : 0u;
+            eofs |= (act && eof) ? (1u << e) : 0u;
+            any |= p[e] < 512u;
+          }
+        }
+        uint4 row;
+        if (CLEN == 8) {
+          uint32_t w3 = 0;
+#pragma unroll
+          for (int e = 0; e < NCH; ++e) w3 |= (nl[e] < 7u ? nl[e] : 7u) << (3 * e);
+          row = make_uint4((p[0] - 512u) | (p[1] - 512u) << 8 | (p[2] - 512u) << 16 | (p[3] - 512u) << 24,
+                           (p[4] - 512u) | (p[NCH > 5 ? 5 : 0] - 512u) << 8 | (p[NCH > 6 ? 6 : 0] - 512u) << 16 | (p[NCH > 7 ? 7 : 0] - 512u) << 24,
+                           (p[NCH > 8 ? 8 : 0] - 512u) | eofs << 16, w3);
+        } else {
+          uint32_t n[NCH];
+#pragma unroll
+          for (int e = 0; e < NCH; ++e) n[e] = nl[e] < 255u ? nl[e] : 255u;
+          row = make_uint4((p[0] - 512u) | (p[1] - 512u) << 8 | (p[2] - 512u) << 16 | (p[3] - 512u) << 24,
+                           (p[4] - 512u) | n[0] << 8 | n[1] << 16 | n[2] << 24, n[3] | n[4] << 8 | eofs << 16, 0u);
+        }
+        *reinterpret_cast<uint4*>(tab + sub * stride) = row;
+      };
+      if (CL.L == 8) walk(std::integral_constant<int, 8>{});
+      else walk(std::integral_constant<int, 4>{});
       continue;
     }
     const uint32_t hi = lo + kSubBits < limit ? lo + kSubBits : limit;  // (behind the stream's end nothing is decoded)
@@ -1226,13 +1284,13 @@ __global__ __launch_bounds__(64) void k_fn_reduce(const uint8_t* __restrict__ f,
 
 // one level down: start[64 t + j] = offset at which the true decode enters element j of tile t, given where it enters the
 // tile.  The lowest level writes the subsequences' start offsets themselves (16-bit, P.start; [0] keeps the caller's value).
-// With byte classes (*byte_flag, see k_sync_table) the lowest level also SETTLES the subsequences below n_settle: count and
+// With classes (*cls_flag = L, see k_sync_table) the lowest level also SETTLES the subsequences below n_settle: count and
 // "computed from this entry offset" as k_sync_pass would leave them, unless the row says that the chain from this entry
 // met an end mark or more 9-bit codes than the row counts.
 template <typename OutT>
 __global__ __launch_bounds__(64) void k_fn_apply(const uint8_t* __restrict__ f, uint64_t n, uint32_t stride,
                                                  const uint8_t* __restrict__ tile_start, uint32_t entry, OutT* __restrict__ start,
-                                                 const uint32_t* __restrict__ byte_flag, uint64_t n_settle, uint32_t* __restrict__ cnt_out,
+                                                 const uint32_t* __restrict__ cls_flag, uint64_t n_settle, uint32_t* __restrict__ cnt_out,
                                                  uint16_t* __restrict__ used_out, uint8_t* __restrict__ eof_out) {
   __shared__ __attribute__((aligned(16))) uint8_t fl[64 * 64];
   __shared__ uint8_t st[64];
@@ -1252,13 +1310,21 @@ __global__ __launch_bounds__(64) void k_fn_apply(const uint8_t* __restrict__ f, 
   }
   __syncthreads();
   if (lane < cnt && (sizeof(OutT) == 1 || first + lane != 0)) start[first + lane] = (OutT)st[lane];
-  if (sizeof(OutT) == 2 && byte_flag && lane < cnt && first + lane < n_settle && *byte_flag) {
+  const uint32_t clen = (sizeof(OutT) == 2 && cls_flag) ? *cls_flag : 0u;
+  if (clen && lane < cnt && first + lane < n_settle) {
     const uint32_t e = st[lane];
     const uint8_t* const row = fl + lane * stride;
-    const uint32_t n9 = (*reinterpret_cast<const uint32_t*>(row + 12) >> (3u * e)) & 7u;
     const uint32_t eofs = (*reinterpret_cast<const uint16_t*>(row + 10) >> e) & 1u;
-    if (e <= 8u && n9 != 7u && !eofs) {  // bits from the entry offset to the landing bit = 8 per code + 1 per 9-bit code
-      cnt_out[first + lane] = ((uint32_t)kSubBits + row[e] - e - n9) >> 3;
+    uint32_t nl, full;  // (L + 1)-bit codes on the chain from e; the value that stands for "or more"
+    if (clen == 8u) {
+      nl = (*reinterpret_cast<const uint32_t*>(row + 12) >> (3u * e)) & 7u;
+      full = 7u;
+    } else {
+      nl = row[5u + (e < 5u ? e : 0u)];
+      full = 255u;
+    }
+    if (e <= clen && nl != full && !eofs) {  // bits from the entry offset to the landing bit = L per code + 1 per long code
+      cnt_out[first + lane] = ((uint32_t)kSubBits + row[e] - e - nl) / clen;
       used_out[first + lane] = (uint16_t)e;
       eof_out[first + lane] = 0;  // (a pass that ran on an earlier guess may have seen a fake end mark here)
     }
@@ -1272,7 +1338,7 @@ size_t sync_scan_workspace(uint64_t nsub) {
     if (n <= 1) break;
     n = (n + 63) / 64;
   }
-  return (size_t)(total * (64 + 1) + 256 * 33);  // functions (<= 64 bytes) + entry offsets of every level, each level 256-aligned, + the byte-class flag
+  return (size_t)(total * (64 + 1) + 256 * 33);  // functions (<= 64 bytes) + entry offsets of every level, each level 256-aligned, + the class flag
 }
 
 static uint32_t k6_blocks(uint64_t nsub) {
@@ -1301,8 +1367,8 @@ void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride, uint32_
     st[l] = q;
     q += (cnt[l] + 255) & ~(uint64_t)255;
   }
-  uint32_t* const byte_flag = reinterpret_cast<uint32_t*>(q);
-  hipLaunchKernelGGL(k_sync_table, dim3(k6_blocks(p.nsub)), dim3(kK6Threads), 0, s, p, stride, fn[0], byte_flag);
+  uint32_t* const cls_flag = reinterpret_cast<uint32_t*>(q);
+  hipLaunchKernelGGL(k_sync_table, dim3(k6_blocks(p.nsub)), dim3(kK6Threads), 0, s, p, stride, fn[0], cls_flag);
   for (int l = 0; l + 1 < levels; ++l)
     hipLaunchKernelGGL(k_fn_reduce, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], stride, fn[l + 1]);
   // the top level has one element: the whole body, entered at bit `entry` (< stride) of its first subsequence
@@ -1315,12 +1381,12 @@ void launch_sync_scan(const SyncParams& p, uint8_t* ws, uint32_t stride, uint32_
   for (int l = levels - 2; l >= 1; --l)
     hipLaunchKernelGGL(k_fn_apply<uint8_t>, dim3((uint32_t)cnt[l + 1]), dim3(64), 0, s, fn[l], cnt[l], stride, st[l + 1], 0u, st[l], no_flag,
                        0ull, (uint32_t*)nullptr, (uint16_t*)nullptr, (uint8_t*)nullptr);
-  // settled by the lowest level (byte classes only): whole groups of 64 subsequences, and never the last subsequence (its
+  // settled by the lowest level (class codes only): whole groups of 64 subsequences, and never the last subsequence (its
   // landing bit, the end of a piece and the end mark are k_sync_pass's)
   uint64_t n_settle = (p.end_bit - p.body_bit0) / (64ull * kSubBits) * 64ull;
   if (n_settle > p.nsub - 1) n_settle = p.nsub - 1;
   hipLaunchKernelGGL(k_fn_apply<uint16_t>, dim3((uint32_t)cnt[1]), dim3(64), 0, s, fn[0], cnt[0], stride, st[1], 0u, p.start,
-                     (const uint32_t*)byte_flag, (unsigned long long)n_settle, p.cnt, p.used, p.eof);
+                     (const uint32_t*)cls_flag, (unsigned long long)n_settle, p.cnt, p.used, p.eof);
 }
 
 // first subsequence that holds the end mark (valid once the passes have converged)
@@ -1347,7 +1413,7 @@ __global__ __launch_bounds__(256) void k_sync_tile_sums(SyncParams P) {
 __global__ __launch_bounds__(kK6Threads, 4) void k_sync_index(SyncParams P, uint64_t* __restrict__ seg_abs, uint64_t n_segs, uint64_t n_symbols) {
   GHF_K6_PROLOGUE();
   (void)ngroups;
-  const K6Byte BY = k6_byte(k6_mode, P.dt->min_len, max_len, C2, P.body_bit0);
+  const K6Cls CL = k6_cls(k6_mode, P.dt->min_len, max_len, C2, P.body_bit0);
   __shared__ unsigned long long wsum[kK6Waves];
   const uint64_t eof_sub = *P.eof_sub;
   const uint64_t ntrips = (P.nsub + kK6Threads - 1) / kK6Threads;
@@ -1374,33 +1440,38 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_index(SyncParams P, uint
     wave_sync();
     const uint32_t limit = k6_limit(body_bits, g);
     const uint64_t abs0 = P.body_bit0 + g * 64 * kSubBits;  // stream bit of the wave's first subsequence
-    if (MODE == 2 && BY.on && limit >= 64u * kSubBits) {  // byte classes (wave-uniform): the true chain as a walk over the class masks
-      uint64_t F[8], G[8];
-      k6_classes<false>(lin, la0, base + (uint32_t)lane * kSubBits, 0u, F, G);
-      uint64_t* const Fl = k6_f_slot(L, tid);
+    if (MODE == 2 && CL.L && limit >= 64u * kSubBits) {  // class codes (wave-uniform): the true chain as a walk over the class masks
+      auto walk = [&](auto l_tag) {
+        constexpr int CLEN = decltype(l_tag)::value;
+        uint64_t F[8], G[8];
+        k6_classes<CLEN, false>(lin, la0, base + (uint32_t)lane * kSubBits, 0u, F, G);
+        uint64_t* const Fl = k6_f_slot(L, tid);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) Fl[r * kK6Threads] = F[r];
-      if (!valid || c == 0u) continue;
-      // symbol number `mark` of the chain is the first of a segment, symbol number c the first one that is not counted here
-      const uint32_t mark = (uint32_t)((64u - (uint32_t)(first & 63u)) & 63u);
-      const bool last = first + c == n_symbols;
-      uint32_t p = P.start[sub], k0 = 0, p_mark = 0, p_end = 0;
-      while (k0 < c) {  // one run of 8-bit codes, closed by a 9-bit code or by the end of the subsequence
-        const uint32_t r = p & 7u, i = (p >> 3) & 63u;
-        const uint64_t m = Fl[r * kK6Threads] << i;
-        const bool found = m != 0;
-        const uint32_t z = (uint32_t)__builtin_clzll(m | 1ull);
-        const uint32_t run = found ? z + 1u : 64u - i;  // codes in it
-        if (mark >= k0 && mark < k0 + run) p_mark = p + 8u * (mark - k0);
-        if (c <= k0 + run) p_end = p + 8u * (c - k0) + ((found && c == k0 + run) ? 1u : 0u);
-        p = found ? p + 8u * z + 9u : (512u | r) + 8u * 0u;
-        k0 += run;
-        if (!found) break;  // (the chain has left the subsequence: c <= k0 by the count's definition)
-      }
-      const uint32_t lo = (uint32_t)lane * kSubBits;
-      const uint64_t seg = (first + mark) >> 6;
-      if (mark < c && seg < n_segs) seg_abs[seg] = abs0 + lo + p_mark;
-      if (last) seg_abs[n_segs] = abs0 + lo + p_end;  // where the last data symbol ends
+        for (int r = 0; r < 8; ++r) Fl[r * kK6Threads] = F[r];
+        if (!valid || c == 0u) return;
+        // symbol numbers m0 (and, L = 4, m0 + 64) of the chain are the first of a segment, symbol number c the first one
+        // that is not counted here
+        const uint32_t m0 = (uint32_t)((64u - (uint32_t)(first & 63u)) & 63u);
+        const uint32_t lo = (uint32_t)lane * kSubBits;
+        uint32_t p = P.start[sub], k0 = 0, p_end = 0;
+        while (k0 < c) {  // one run of L-bit codes, closed by an (L + 1)-bit code or by the end of the subsequence
+          bool found, eof;
+          const uint32_t sh = k6_jump<CLEN, false>([&](uint32_t c) { return Fl[c * kK6Threads]; }, [](uint32_t) { return 0ull; }, p, found, eof);
+          const uint32_t run = found ? sh + 1u : sh;  // codes in it
+#pragma unroll
+          for (uint32_t m = m0; m < 64u * (8u / (uint32_t)CLEN); m += 64u) {
+            const uint64_t seg = (first + m) >> 6;
+            if (m >= k0 && m < k0 + run && m < c && seg < n_segs) seg_abs[seg] = abs0 + lo + p + (uint32_t)CLEN * (m - k0);
+          }
+          if (c <= k0 + run) p_end = p + (uint32_t)CLEN * (c - k0) + ((found && c == k0 + run) ? 1u : 0u);
+          p += (uint32_t)CLEN * sh + (uint32_t)CLEN + 1u;
+          k0 += run;
+          if (!found) break;  // (the chain has left the subsequence: c <= k0 by the count's definition)
+        }
+        if (first + c == n_symbols) seg_abs[n_segs] = abs0 + lo + p_end;  // where the last data symbol ends
+      };
+      if (CL.L == 8) walk(std::integral_constant<int, 8>{});
+      else walk(std::integral_constant<int, 4>{});
       continue;
     }
     if (!valid) continue;

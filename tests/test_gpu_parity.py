@@ -188,11 +188,12 @@ def test_foreign_stream_16MiB(env, kind):
     assert np.array_equal(out[:n].cpu().numpy(), data)
 
 
-def _bytes_that_do_not_compress(n, rare, seed):
-    """every byte value equally often, `rare` a little less: 255 codes of 8 bits, 9 bits for `rare` and the end mark"""
+def _bytes_that_do_not_compress(n, rare, seed, values=256):
+    """every one of `values` byte values equally often, `rare` a little less: values - 1 codes of log2(values) bits, one bit
+    more for `rare` and the end mark"""
     rng = np.random.default_rng(seed)
-    per = n // 256
-    data = np.repeat(np.arange(256, dtype=np.uint8), per)
+    per = n // values
+    data = np.repeat(np.arange(values, dtype=np.uint8), per)
     data = data[np.logical_or(data != rare, np.arange(data.size) % 8 != 0)]  # `rare`: 7/8 of the others' count
     return rng.permutation(data)
 
@@ -223,6 +224,38 @@ def test_foreign_stream_of_8_and_9_bit_codes(env, case):
     crs = orc.compress(data)
     code, hs = ghf.parse_header(crs)
     assert (code.min_len, code.max_len) == (8, 9)
+    stream = crs
+    if case == "bytes_behind_the_end_mark":
+        stream = np.concatenate([crs, np.random.default_rng(5).integers(0, 256, 100000, dtype=np.uint8)])
+    d_stream = to_dev(torch, np.concatenate([stream, np.zeros(64, np.uint8)]))
+    out, nout = ctx.decode(d_stream, stream.size, ctx.code_to_device(code), None, cap=data.size + 4096)
+    ctx.sync()
+    assert int(nout.item()) == data.size
+    assert np.array_equal(out[: data.size].cpu().numpy(), data)
+
+
+@pytest.mark.parametrize("case", ["shuffled", "sorted", "rare_in_runs", "rare_15", "bytes_behind_the_end_mark", "one_group", "tiny"])
+def test_foreign_stream_of_4_and_5_bit_codes(env, case):
+    """the same classes one size down (16 equally likely values + the end mark: 15 codes of 4 bits, two of 5): a chain
+    alternates between two residue classes mod 8; two segment starts can fall into one 512-bit subsequence."""
+    ghf, ctx, torch = env
+    n = {"one_group": 9000, "tiny": 31}.get(case, (3 << 20) + 777)
+    rare = 15 if case == "rare_15" else (0 if case == "sorted" else 9)
+    if n == 31:  # every value twice, `rare` once
+        data = np.random.default_rng(3).permutation(np.delete(np.repeat(np.arange(16, dtype=np.uint8), 2), 2 * rare))
+    else:
+        data = _bytes_that_do_not_compress(n, rare, seed=n % 1000, values=16)
+    if case == "sorted":
+        data = np.sort(data)
+    if case == "rare_in_runs":
+        data = data.copy()
+        data[1000:1700] = rare
+        data[200000:200130] = rare
+        keep = np.flatnonzero(data == rare)
+        data = np.delete(data, keep[keep >= 300000][:820])
+    crs = orc.compress(data)
+    code, hs = ghf.parse_header(crs)
+    assert (code.min_len, code.max_len) == (4, 5)
     stream = crs
     if case == "bytes_behind_the_end_mark":
         stream = np.concatenate([crs, np.random.default_rng(5).integers(0, 256, 100000, dtype=np.uint8)])
