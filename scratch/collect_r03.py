@@ -23,7 +23,7 @@ def short(name):
 
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench.json"))
 for mib, name in ((256, "256MiB"), (4096, "4GiB")):
-    for f in glob.glob(os.path.join(src, "stats%d" % mib, "**", "*kernel_stats.csv"), recursive=True):
+    for f in sorted(glob.glob(os.path.join(src, "stats%d" % mib, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime):
         shutil.copy(f, os.path.join(dst, "kernel_stats_%s.csv" % name))
 traffic = {"_note": "HBM bytes per launch from the rocprofv3 PMC passes in profiles/%s/pmc_*.csv (uniform bytes): "
                     "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section "
@@ -55,7 +55,7 @@ for mib, name in ((256, "256MiB"), (4096, "4GiB")):
             w.writerow(row)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 for kind in ("uniform", "zipf", "sym16"):
-    for f in glob.glob(os.path.join(src, "foreign_%s" % kind, "**", "*kernel_stats.csv"), recursive=True):
+    for f in sorted(glob.glob(os.path.join(src, "foreign_%s" % kind, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime):
         shutil.copy(f, os.path.join(dst, "foreign_decode_kernel_stats_%s.csv" % kind))
 for f in ("file_perf.json", "membench.txt", "bench_256MiB_zipf.json", "bench_256MiB_sym16.json", "pipe_trace_reuse_uniform.log",
           "pipe_trace_reuse_zipf.log"):
