@@ -874,6 +874,27 @@ __device__ __forceinline__ uint32_t k6_step(K6Cursor& c, const uint8_t* lin, con
   return c.step(lin, L, T, MODE == 1 ? -1 : lut_bits, max_len);
 }
 
+// Two codes of at most 16 bits behind ONE refill check (table + miss path, or table only): their entries; the window may
+// move, the position (o) does not -- the caller commits one or both.  Half the refill / bounds / end-mark tests of two
+// single steps: the generic K6 loops run at 2.3x K7's time per decoded symbol, and most of that is tests, not lookups.
+template <int MODE>
+__device__ __forceinline__ void k6_peek2(K6Cursor& c, const uint8_t* lin, const DecLds7& L, const DecLut& T, int lut_bits, int max_len,
+                                         uint32_t& e0, uint32_t& e1) {
+  static_assert(MODE == 0 || MODE == 1, "two-length codes step by comparison");
+  if (c.o >= 32u) {
+    c.W = (c.W << 32) | c.nextw;
+    c.o -= 32u;
+    c.nextw = in_word(lin, c.la);
+    c.la += 4u;
+  }
+  const uint32_t v0 = (uint32_t)((c.W << c.o) >> 32);
+  e0 = dec_lookup(T, v0);
+  if (MODE == 0 && (e0 & kEntNone)) e0 = dec_long_entry(L, v0, lut_bits, max_len);
+  const uint32_t v1 = (uint32_t)((c.W << (c.o + ((e0 >> 8) & 0xFFu))) >> 32);  // (o < 32, a code <= 16 bits: >= 16 valid bits)
+  e1 = dec_lookup(T, v1);
+  if (MODE == 0 && (e1 & kEntNone)) e1 = dec_long_entry(L, v1, lut_bits, max_len);
+}
+
 // stage the bits of 64 consecutive subsequences (+ look-ahead) of the body into the wave's padded tile (big-endian
 // words, zeros behind the stream); returns the bit offset of subsequence `sub0` inside the tile
 __device__ __forceinline__ uint32_t k6_stage(const SyncParams& P, uint64_t sub0, uint8_t* lin, uint32_t la0, int lane) {
@@ -1084,11 +1105,24 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
       const uint32_t sub_lo = (uint32_t)lane * kSubBits;  // relative to the wave's first subsequence
       const uint32_t sub_hi = sub_lo + kSubBits;
       const uint32_t limit = k6_limit(body_bits, g);
+      const bool pairs = max_len <= 16 && limit >= 64u * kSubBits;  // (wave-uniform: short codes, every subsequence whole)
       uint32_t pos = sub_lo + st;
       uint32_t count = 0;
       bool eof = false;
       K6Cursor cur;
       cur.open(lin, la0, base + pos);
+      if (MODE != 2 && pairs) {  // two codes per round while neither is an end mark; what is left goes one by one below
+        while (pos < sub_hi) {
+          uint32_t e0, e1;
+          k6_peek2<MODE == 2 ? 1 : MODE>(cur, lin, L, T1, lut_bits, max_len, e0, e1);
+          if ((e0 | e1) & kEntEnd) break;
+          const uint32_t l0 = (e0 >> 8) & 0xFFu, l1 = (e1 >> 8) & 0xFFu;
+          const bool both = pos + l0 < sub_hi;  // the second code begins in this subsequence too
+          pos += both ? l0 + l1 : l0;
+          cur.o += both ? l0 + l1 : l0;
+          count += both ? 2u : 1u;
+        }
+      }
       while (pos < sub_hi && pos < limit) {
         const uint32_t ent = k6_step<MODE>(cur, lin, L, T1, lut_bits, max_len, C2);
         if (ent & kEntEnd) {  // the end mark (or bits that are no code)
@@ -1480,13 +1514,27 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_index(SyncParams P, uint
     cur.open(lin, la0, base + pos);
     uint32_t mark = (uint32_t)((64u - (uint32_t)(first & 63u)) & 63u);  // my symbols in front of the next segment start
     uint64_t seg = (first + mark) >> 6;
-    for (uint32_t k = 0; k < c && pos < limit; ++k) {
+    const bool pairs = MODE != 2 && max_len <= 16 && limit >= 64u * kSubBits;  // (wave-uniform; see k_sync_pass)
+    for (uint32_t k = 0; k < c && pos < limit;) {
       if (k == mark) {
         if (seg < n_segs) seg_abs[seg] = abs0 + pos;
         ++seg;
         mark += 64u;
       }
-      pos += (k6_step<MODE>(cur, lin, L, T1, lut_bits, max_len, C2) >> 8) & 0xFFu;
+      const uint32_t stop = c < mark ? c : mark;  // the next symbol number at which something is written
+      if (pairs) {  // (the counts are exact: no end mark among these symbols, none of them behind the stream's end)
+        for (; k + 2u <= stop; k += 2u) {
+          uint32_t e0, e1;
+          k6_peek2<MODE == 2 ? 1 : MODE>(cur, lin, L, T1, lut_bits, max_len, e0, e1);
+          const uint32_t l = ((e0 >> 8) & 0xFFu) + ((e1 >> 8) & 0xFFu);
+          pos += l;
+          cur.o += l;
+        }
+      }
+      if (k < stop) {
+        pos += (k6_step<MODE>(cur, lin, L, T1, lut_bits, max_len, C2) >> 8) & 0xFFu;
+        ++k;
+      }
     }
     if (c && first + c == n_symbols) seg_abs[n_segs] = abs0 + pos;  // where the last data symbol ends
   }
