@@ -1225,7 +1225,8 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint
             bool found, eof;
             // (L = 8: the long code lies in the chain's own class, its G mask is read WITH the F mask -- one LDS round trip per
             //  jump.  L = 4: it lies in one of two classes; reading both candidates' G masks up front gave wrong end-mark bits
-            //  in this kernel on the GPU -- not in a stand-alone harness of the same function, scratch/jump_gpu_test.hip, and
+            //  in THIS kernel at -O3 -- not at -O1, not with every s_waitcnt forced to zero (so it is not a counted wait), not
+            //  in stand-alone GPU harnesses of the same function and loop, scratch/jump_gpu_test.hip / walk_gpu_test.hip, and
             //  not on the host -- which is not root-caused; the mask of the class the jump arrives in is read behind it.)
             const uint32_t sh = k6_jump<CLEN, CLEN == 8>([&](uint32_t c) { return Fl[c * kK6Threads]; }, [&](uint32_t c) { return Gl[c * 64]; }, pe, found, eof);
             const uint32_t q = pe + (uint32_t)CLEN * sh;
