@@ -1046,9 +1046,12 @@ __device__ __forceinline__ void k6_classes(const uint8_t* lin, uint32_t la0, uin
 }
 // where the masks of a wave's 64 subsequences live while its chains walk: F in the (unused) table area, [class][thread];
 // G in the wave's own tile, whose bytes are in registers by then, [class][lane]
-__device__ __forceinline__ uint64_t* k6_f_slot(DecLds7& L, int tid) { return reinterpret_cast<uint64_t*>(L.lut) + tid; }
-__device__ __forceinline__ uint64_t* k6_g_slot(DecLds7& L, int wave, int lane) {
-  return reinterpret_cast<uint64_t*>(L.in + (uint32_t)wave * kDec7TilePhys) + lane;
+// (the masks are 64-bit words in arrays that are declared, and elsewhere accessed, as 32-bit words and bytes: may_alias
+//  tells the compiler so -- without it type-based alias analysis may order these accesses freely against the others)
+typedef uint64_t __attribute__((may_alias)) k6_mask_t;
+__device__ __forceinline__ k6_mask_t* k6_f_slot(DecLds7& L, int tid) { return reinterpret_cast<k6_mask_t*>(L.lut) + tid; }
+__device__ __forceinline__ k6_mask_t* k6_g_slot(DecLds7& L, int wave, int lane) {
+  return reinterpret_cast<k6_mask_t*>(L.in + (uint32_t)wave * kDec7TilePhys) + lane;
 }
 static_assert(sizeof(DecLds7::lut) >= 8 * kDec7Threads * sizeof(uint64_t) && kDec7TilePhys >= 8 * 64 * (int)sizeof(uint64_t) && kDec7TilePhys % 8 == 0,
               "room for the class masks");
@@ -1196,8 +1199,8 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint
         uint64_t F[8], G[8];
         k6_classes<CLEN, true>(lin, la0, base + lo, CL.eof_bit, F, G);
         wave_sync();  // (every lane has its bytes: the tile may take the G masks)
-        uint64_t* const Fl = k6_f_slot(L, tid);
-        uint64_t* const Gl = k6_g_slot(L, wave, lane);
+        k6_mask_t* const Fl = k6_f_slot(L, tid);
+        k6_mask_t* const Gl = k6_g_slot(L, wave, lane);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           Fl[r * kK6Threads] = F[r];
@@ -1227,7 +1230,8 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_table(SyncParams P, uint
             //  jump.  L = 4: it lies in one of two classes; reading both candidates' G masks up front gave wrong end-mark bits
             //  in THIS kernel at -O3 -- not at -O1, not with every s_waitcnt forced to zero (so it is not a counted wait), not
             //  in stand-alone GPU harnesses of the same function and loop, scratch/jump_gpu_test.hip / walk_gpu_test.hip, and
-            //  not on the host -- which is not root-caused; the mask of the class the jump arrives in is read behind it.)
+            //  not on the host -- which is not root-caused; that build is also the only one that spills (4 VGPRs).  The mask
+            //  of the class the jump arrives in is read behind it, and tests/test_cabi_cpu.py keeps this kernel scratch-free.)
             const uint32_t sh = k6_jump<CLEN, CLEN == 8>([&](uint32_t c) { return Fl[c * kK6Threads]; }, [&](uint32_t c) { return Gl[c * 64]; }, pe, found, eof);
             const uint32_t q = pe + (uint32_t)CLEN * sh;
             if (CLEN == 4) eof = found && ((Gl[(q & 7u) * 64] << ((q >> 3) & 63u)) >> 63) != 0;
@@ -1480,7 +1484,7 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_index(SyncParams P, uint
         constexpr int CLEN = decltype(l_tag)::value;
         uint64_t F[8], G[8];
         k6_classes<CLEN, false>(lin, la0, base + (uint32_t)lane * kSubBits, 0u, F, G);
-        uint64_t* const Fl = k6_f_slot(L, tid);
+        k6_mask_t* const Fl = k6_f_slot(L, tid);
 #pragma unroll
         for (int r = 0; r < 8; ++r) Fl[r * kK6Threads] = F[r];
         if (!valid || c == 0u) return;

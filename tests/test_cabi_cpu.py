@@ -202,6 +202,18 @@ def test_emit_main_loops_have_counted_waits_and_no_scratch():
     assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) == 0
 
 
+def test_k6_kernels_use_no_scratch():
+    """Twice now a build of one of these LDS-heavy kernels that SPILLED gave wrong streams on the GPU where its non-spilling
+    twin did not (round 1: k_emit with 6 spilled VGPRs; round 3: k_sync_table with 4, the build that read both candidate
+    end-mark masks of the 4/5-bit class walk up front; neither root-caused).  The K6 kernels are kept
+    scratch-free: a change that makes one of them spill fails here, on the CPU, before it can fail on a GPU."""
+    text = _kernel_asm("ghf_decode")
+    for sym in ("_ZN3ghf12k_sync_tableENS_10SyncParamsEjPhPj", "_ZN3ghf11k_sync_passENS_10SyncParamsE", "_ZN3ghf12k_sync_indexENS_10SyncParamsEPmmm"):
+        meta = re.search(r"\.name:\s+%s\b(.*?)\.wavefront_size" % re.escape(sym), text, flags=re.S).group(1)
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1)) == 0, sym
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) == 0, sym
+
+
 def test_decode_kernel_scratch_reloads_are_followed_by_full_waits():
     text = _kernel_asm("ghf_decode")
     # K7 may spill (its 128-VGPR budget is tight), but only where it does no harm: every scratch reload must be
