@@ -57,7 +57,7 @@ json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), in
 for kind in ("uniform", "zipf", "sym16"):
     for f in sorted(glob.glob(os.path.join(src, "foreign_%s" % kind, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime):
         shutil.copy(f, os.path.join(dst, "foreign_decode_kernel_stats_%s.csv" % kind))
-for f in ("file_perf.json", "membench.txt", "bench_256MiB_zipf.json", "bench_256MiB_sym16.json", "pipe_trace_reuse_uniform.log",
+for f in ("file_perf.json", "membench.txt", "bench_256MiB_zipf.json", "bench_256MiB_sym16.json", "bench_4GiB_uniform.json", "bench_4GiB_zipf.json", "pipe_trace_reuse_uniform.log",
           "pipe_trace_reuse_zipf.log"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))

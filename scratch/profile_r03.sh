@@ -32,6 +32,9 @@ echo "== the other 256 MiB inputs"
 for KIND in zipf sym16; do
   python3 bench.py --steps 100 --kind $KIND --no-configs --no-cpu-baseline > $O/bench_256MiB_$KIND.json 2> /dev/null
 done
+for KIND in uniform zipf; do
+  python3 bench.py --mib 4096 --steps 40 --warmup 2 --kind $KIND --no-configs --no-cpu-baseline > $O/bench_4GiB_$KIND.json 2> /dev/null
+done
 echo "== memory microbenchmark"
 timeout -k 10 300 ./scratch/membench > $O/membench.txt 2>&1
 echo "== file to file"
