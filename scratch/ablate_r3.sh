@@ -16,15 +16,10 @@ build() {  # name, sed for ghf_decode.hip, sed for ghf_emit.hip, sed for ghf_ker
   rm -rf $T
   echo built $1
 }
-# K7: what bounds it?  (scratch/ablate_run.py times k_decode alone.)  These five builds were made from the tree that had the
-# byte-phase decoder in it (VAR 6, profiles/r03/experiments/k7_byte_phases_decoder.hip.txt; logs: k7_ablate_*.log beside it):
-# base = byte phases, k7_generic = the shipped decoder, nodecode / nostore = the memory skeleton.  On the shipped tree only
-# k7_nostore still applies.
+# K1 at 256 MiB: 64 us where a pure read takes 45 -- what do the final reduction and the LDS atomics cost?  (measured once:
+# base 0.0648, without the final global atomics 0.0631, without ANY ds_add 0.0606 ms -- profiles/r03/experiments/k1_ablate_256MiB.log.
+# The builds leave the histogram empty, so everything behind K1 works on garbage: the no-atomics build FAULTED in a later
+# kernel at 4 GiB.  Do not run such a build through ablate_run.py again; time K1 alone.)
 build base "" "" "" &
-build k7_generic 's|  const bool byte_code = P.dt->kind == 0|  const bool byte_code = false \&\& P.dt->kind == 0|' "" "" &
-build k7_nodecode 's|          else if (VAR == 6) acc = dec_hot_bytes(lin, la0, T1, thr8, cur.pos, out, used);|          else if (VAR == 6) { for (int d = 0; d < 16; ++d) out[d] = cur.pos + d; used = cur.expect; acc = 0; }|' "" "" &
-wait
-build k7_nostore 's|            store_stream(og + r \* 1024, \*reinterpret_cast<const uint4\*>(tile + sl \* 16 + piece \* 4));|            if (P.n_symbols == 1) store_stream(og + r * 1024, *reinterpret_cast<const uint4*>(tile + sl * 16 + piece * 4));|' "" "" &
-build k7_nodecode_nostore 's|          else if (VAR == 6) acc = dec_hot_bytes(lin, la0, T1, thr8, cur.pos, out, used);|          else if (VAR == 6) { for (int d = 0; d < 16; ++d) out[d] = cur.pos + d; used = cur.expect; acc = 0; }|;s|            store_stream(og + r \* 1024, \*reinterpret_cast<const uint4\*>(tile + sl \* 16 + piece \* 4));|            if (P.n_symbols == 1) store_stream(og + r * 1024, *reinterpret_cast<const uint4*>(tile + sl * 16 + piece * 4));|' "" "" &
 wait
 ls $R/scratch/exp/
