@@ -16,10 +16,14 @@ build() {  # name, sed for ghf_decode.hip, sed for ghf_emit.hip, sed for ghf_ker
   rm -rf $T
   echo built $1
 }
-# K1 at 256 MiB: 64 us where a pure read takes 45 -- what do the final reduction and the LDS atomics cost?  (measured once:
-# base 0.0648, without the final global atomics 0.0631, without ANY ds_add 0.0606 ms -- profiles/r03/experiments/k1_ablate_256MiB.log.
-# The builds leave the histogram empty, so everything behind K1 works on garbage: the no-atomics build FAULTED in a later
-# kernel at 4 GiB.  Do not run such a build through ablate_run.py again; time K1 alone.)
+# K7's bookkeeping: the bare memory skeleton (scratch/membench3.hip) takes 0.092 / 1.61 ms, K7 without its decode 0.117 / 1.75.
+# Every build below keeps every load and store of the kernel in place (same addresses: nothing can fault), the uniform-bytes
+# decoder replaced by "the bytes a lane decodes are its bit offset" (nodecode) and then ONE piece of bookkeeping removed:
+#   notable   the 64 KiB table replication of the prologue (unused without the decoder)
+#   static    groups by static stride instead of ticket counters
+#   linear    staging without byte swaps and without the padded layout's address arithmetic
+# (the K7 bookkeeping builds of round 3 -- nodecode, nodecode_static, static, 64 / 128 ticket classes -- are in git history and in
+#  profiles/r03/experiments/membench3_k7_skeleton.txt; a "ticket ranges" build ABORTED in the pipelined bench and is not kept)
 build base "" "" "" &
 wait
 ls $R/scratch/exp/
