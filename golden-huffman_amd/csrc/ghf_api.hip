@@ -37,7 +37,7 @@ struct ghf_ctx {
   uint64_t* d_totals = nullptr;  // [totals_cap] per-rank body bits (ghf_encode_sharded)
   int totals_cap = 0;
   uint64_t* d_u64 = nullptr;    // [16] scratch scalars: 0 total_bits, 1..2 end, 3 n_symbols, 4 eof_sub, 5 changed, 6 start bit (.crs), 8 landing
-  uint64_t* h_u64 = nullptr;    // [8] pinned mirror
+  uint64_t* h_u64 = nullptr;    // [16] pinned mirror
   // K6 workspace (foreign streams)
   void* d_sync = nullptr;
   size_t sync_cap = 0;  // bytes
@@ -782,6 +782,16 @@ int ghf_decoded_size(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, c
   return GHF_OK;
 }
 
+// TUNING (round 4, to be fixed by measurement): share of K7's rounds that waves own by stride before tickets take over
+static uint32_t k7_static_permille() {
+  static const uint32_t v = [] {
+    const char* e = std::getenv("GHF_K7_STATIC");
+    long x = e ? std::strtol(e, nullptr, 10) : 0;
+    return (uint32_t)(x < 0 ? 0 : x > 1000 ? 1000 : x);
+  }();
+  return v;
+}
+
 int ghf_decode_prepare(ghf_ctx* c, const ghf_code* d_code) {
   if (!c || !d_code) return GHF_E_INVAL;
   GHF_HIP(c, hipSetDevice(c->device));
@@ -831,6 +841,7 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
   p.n_symbols = index->n_symbols;
   p.n_segs = index->n_segs;
   p.no_end_mark = (index->flags & GHF_INDEX_NO_END_MARK) ? 1u : 0u;
+  p.static_permille = k7_static_permille();
   p.out = d_out;
   p.status = c->d_status;
   p.out_bytes = d_out_bytes;
@@ -930,13 +941,28 @@ int ghf_crs_parse_header(const uint8_t* h, size_t n, ghf_tree* tree, size_t* tre
   return GHF_OK;
 }
 
-static int crs_geometry(ghf_ctx* c, const ghf_tree* d_tree, size_t stream_bytes, int left_bits, size_t* hdr, uint64_t* end_bit) {
+// the depth of a device-resident tree (1..64), for the stride of K6's function rows: 16 / 32 / 64 bytes as for .crs2 -- a
+// shallow tree does not pay for 64-byte rows
+static int crs_max_len(ghf_ctx* c, const ghf_tree* d_tree, int* max_len) {
+  hipError_t e = hipMemcpyAsync(c->h_u64 + 9, &d_tree->max_len, sizeof(d_tree->max_len), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail(c, GHF_E_HIP, "copy the tree's max_len to host", e);
+  uint32_t ml = 0;
+  std::memcpy(&ml, c->h_u64 + 9, sizeof ml);
+  *max_len = (ml >= 1 && ml <= 64) ? (int)ml : 64;  // (anything else is refused by k_crs_decode_tables)
+  return GHF_OK;
+}
+
+static int crs_geometry(ghf_ctx* c, const ghf_tree* d_tree, size_t stream_bytes, int left_bits, size_t* hdr, uint64_t* end_bit, int* max_len) {
   if (left_bits < 0 || left_bits > 7) return fail(c, GHF_E_FORMAT, "left_bits must be 0..7");
-  uint32_t tb = 0;
+  uint32_t tb = 0, ml = 0;
   hipError_t e = hipMemcpyAsync(c->h_u64 + 7, &d_tree->tree_bytes, 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->h_u64 + 9, &d_tree->max_len, sizeof(d_tree->max_len), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return fail(c, GHF_E_HIP, "copy tree_bytes to host", e);
   std::memcpy(&tb, c->h_u64 + 7, 4);
+  std::memcpy(&ml, c->h_u64 + 9, 4);
+  *max_len = (ml >= 1 && ml <= 64) ? (int)ml : 64;
   if (tb < 6 || tb > 1022 || (tb & 1)) return fail(c, GHF_E_FORMAT, "bad tree_bytes");
   *hdr = (size_t)tb + 2;
   if (stream_bytes < *hdr || (left_bits && stream_bytes == *hdr)) return fail(c, GHF_E_FORMAT, "stream shorter than its header");
@@ -951,7 +977,8 @@ int ghf_crs_decoded_size(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
   GHF_HIP(c, hipSetDevice(c->device));
   size_t hdr;
   uint64_t end_bit;
-  int rc = crs_geometry(c, d_tree, stream_bytes, left_bits, &hdr, &end_bit);
+  int depth = 64;
+  int rc = crs_geometry(c, d_tree, stream_bytes, left_bits, &hdr, &end_bit, &depth);
   if (rc) return rc;
   launch_crs_decode_tables(d_tree, c->d_dt, c->d_status, c->stream);
   c->dt_code = nullptr;
@@ -959,7 +986,7 @@ int ghf_crs_decoded_size(ghf_ctx* c, const uint8_t* d_stream, size_t stream_byte
     *n_out = 0;
     return GHF_OK;
   }
-  rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, 1, (size_t)-1, 0, nullptr, nullptr, false, 64);  // (codes up to 64 bits)
+  rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, 1, (size_t)-1, 0, nullptr, nullptr, false, depth);  // (codes up to 64 bits)
   if (rc) return rc;
   *n_out = c->fidx.n_symbols;
   return GHF_OK;
@@ -985,7 +1012,10 @@ int ghf_crs_sync_piece(ghf_ctx* c, const uint8_t* d_piece, size_t piece_bytes, u
     return GHF_OK;
   }
   int bad = 0;  // with the tree's tables "end mark" can only mean: bits that are no code
-  const int rc = rebuild_index_at(c, d_piece, piece_bytes, 0, end_bit, 2, (size_t)-1, first_bit, landing, &bad, false, 64);
+  int depth = 64;
+  int rc = crs_max_len(c, d_tree, &depth);
+  if (rc) return rc;
+  rc = rebuild_index_at(c, d_piece, piece_bytes, 0, end_bit, 2, (size_t)-1, first_bit, landing, &bad, false, depth);
   if (rc) return rc;
   if (bad) return fail(c, GHF_E_CORRUPT, "the .crs body holds bits that are no code");
   *n_symbols = c->fidx.n_symbols;
@@ -1003,13 +1033,14 @@ int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int
     if (c->fidx_stream != d_stream || c->fidx_bytes != stream_bytes) {  // else: ghf_crs_decoded_size / ghf_crs_sync_piece did it
       size_t hdr;
       uint64_t end_bit;
-      int rc = crs_geometry(c, d_tree, stream_bytes, left_bits, &hdr, &end_bit);
+      int depth = 64;
+      int rc = crs_geometry(c, d_tree, stream_bytes, left_bits, &hdr, &end_bit, &depth);
       if (rc) return rc;
       if (end_bit == (uint64_t)hdr * 8) {
         if (d_out_bytes) launch_store_u64(d_out_bytes, nullptr, 0, c->stream);
         return GHF_OK;
       }
-      rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, 1, cap, 0, nullptr, nullptr, false, 64);
+      rc = rebuild_index_at(c, d_stream, stream_bytes, hdr, end_bit, 1, cap, 0, nullptr, nullptr, false, depth);
       if (rc) return rc;
     }
     c->fidx_stream = nullptr;
@@ -1033,6 +1064,7 @@ int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int
   p.seg_bit = index->d_seg_bit;
   p.n_symbols = index->n_symbols;
   p.n_segs = index->n_segs;
+  p.static_permille = k7_static_permille();
   p.no_end_mark = 1u;  // there is none in this format; the end of every segment but the last is checked against the side-car
   p.out = d_out;
   p.status = c->d_status;

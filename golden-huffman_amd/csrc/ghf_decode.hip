@@ -11,12 +11,43 @@ namespace ghf {
 // to min(max_len, 12) bits so that no linear extension is needed at any BASELINE config; longer
 // codes fall back to the reference's linear search over first_code (cfind, canonical_huff_encoder.h:157-162).
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t kEntEnd = 1u << 16, kEntNone = 1u << 17;
+__device__ __forceinline__ uint32_t dec7_entry(uint32_t g) {  // compact entry (sym | len << 9) -> image entry
+  const uint32_t sym = g & 0x1FFu, len = g >> 9;
+  return (sym & 0xFFu) | (len << 8) | (sym == 256u ? kEntEnd : 0u) | (len == 0u ? kEntNone : 0u);
+}
+// DecTables::image from the compact tables (LDS): every table has at least four copies of an entry side by side, so the
+// image is written 16 bytes at a time
+__device__ __forceinline__ void dec_image_fill(DecTables* __restrict__ dt, const uint16_t* lut, const uint32_t* lut2, int lb, int pb, int tid,
+                                               int nthreads) {
+  uint4* const img4 = reinterpret_cast<uint4*>(dt->image);
+  if (pb) {
+    const int r2 = (kDec7LutLog2 - pb) < 5 ? (kDec7LutLog2 - pb) : 5;
+    for (int g = tid; g < (1 << (pb + r2 - 2)); g += nthreads) {
+      const uint32_t e = lut2[(4 * g) >> r2];
+      img4[g] = make_uint4(e, e, e, e);
+    }
+    for (int g = tid; g < kDec7SmallSlots / 4; g += nthreads) {
+      const uint32_t e = dec7_entry(lut[((4 * g) >> 5) & ((1 << lb) - 1)]);
+      img4[kDec7LutSlots / 4 + g] = make_uint4(e, e, e, e);
+    }
+  } else {
+    const int r1 = (kDec7LutLog2 - lb) < 5 ? (kDec7LutLog2 - lb) : 5;
+    for (int g = tid; g < (1 << (lb + r1 - 2)); g += nthreads) {
+      const uint32_t e = dec7_entry(lut[(4 * g) >> r1]);
+      img4[g] = make_uint4(e, e, e, e);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_build_decode_tables(const ghf_code* __restrict__ code, DecTables* __restrict__ dt,
                                                              int* __restrict__ status) {
   __shared__ uint32_t fcl[36];
   __shared__ uint32_t sp[36];
   __shared__ unsigned long long kraft;
   __shared__ int bad;
+  __shared__ uint16_t s_lut[1 << kDecLutBitsMax];    // sym | len << 9 ; 0 = code longer than lut_bits
+  __shared__ uint32_t s_lut2[1 << kDecPairBitsMax];  // sym0 | sym1 << 8 | (len0 + len1) << 16 ; bit 30 = not two data symbols
   const int tid = threadIdx.x;
   const int max_len = code->max_len, min_len = code->min_len;
   if (max_len < 1 || max_len > 32 || min_len < 1 || min_len > max_len) {
@@ -68,33 +99,21 @@ __global__ __launch_bounds__(256) void k_build_decode_tables(const ghf_code* __r
     dt->start_pos[tid] = p;
   }
   for (int i = tid; i < GHF_NSYM; i += 256) dt->symbol[i] = (uint16_t)(code->symbol[i] > 256u ? 256u : code->symbol[i]);
+  // two symbols per lookup when any two codes fit the index (small alphabets: 16-symbol data has max_len 5)
+  const int pb = 2 * max_len <= kDecPairBitsMax ? 2 * max_len : 0;
   if (tid == 0) {
     dt->min_len = min_len;
     dt->max_len = max_len;
     dt->lut_bits = lb;
+    dt->pair_bits = pb;
     dt->kind = 0;
     dt->root = 0;
+    dt->done = 0;
   }
   if (tid < 16) dt->ticket[tid * 32] = 0;
   __syncthreads();
-  for (uint32_t idx = tid; idx < (1u << lb); idx += 256) {
-    const uint32_t v = idx << (32 - lb);
-    uint16_t ent = 0;
-    for (int len = min_len; len <= lb; ++len) {
-      if (v >= fcl[len]) {
-        const uint32_t k = sp[len] + ((v - fcl[len]) >> (32 - len));
-        const uint32_t sym = k < GHF_NSYM ? code->symbol[k] : 256u;
-        ent = (uint16_t)((sym > 256u ? 256u : sym) | ((uint32_t)len << 9));
-        break;
-      }
-    }
-    dt->lut[idx] = ent;
-  }
-  // two symbols per lookup when any two codes fit the index (small alphabets: 16-symbol data has max_len 5)
-  const int pb = 2 * max_len <= kDecPairBitsMax ? 2 * max_len : 0;
-  if (tid == 0) dt->pair_bits = pb;
-  auto one = [&](uint32_t v) -> uint32_t {  // sym | len << 9 of the code at the top of v; 0: none
-    for (int len = min_len; len <= max_len; ++len) {
+  auto one = [&](uint32_t v, int upto) -> uint32_t {  // sym | len << 9 of the code of <= upto bits at the top of v; 0: none
+    for (int len = min_len; len <= upto; ++len) {
       if (v >= fcl[len]) {
         const uint32_t k = sp[len] + ((v - fcl[len]) >> (32 - len));
         const uint32_t sym = k < GHF_NSYM ? code->symbol[k] : 256u;
@@ -103,18 +122,21 @@ __global__ __launch_bounds__(256) void k_build_decode_tables(const ghf_code* __r
     }
     return 0u;
   };
+  for (uint32_t idx = tid; idx < (1u << lb); idx += 256) s_lut[idx] = (uint16_t)one(idx << (32 - lb), lb);
   for (uint32_t idx = tid; pb && idx < (1u << pb); idx += 256) {
     const uint32_t v = idx << (32 - pb);
-    const uint32_t e0 = one(v);
+    const uint32_t e0 = one(v, max_len);
     uint32_t ent = (1u << 30) | (1u << 16);  // not a data symbol: flagged, one bit consumed
     if (e0 && (e0 & 0x1FFu) != 256u) {
       const uint32_t l0 = e0 >> 9;
-      const uint32_t e1 = one(v << l0);
+      const uint32_t e1 = one(v << l0, max_len);
       if (e1 && (e1 & 0x1FFu) != 256u) ent = (e0 & 0xFFu) | ((e1 & 0xFFu) << 8) | ((l0 + (e1 >> 9)) << 16);
       else ent = (1u << 30) | (l0 << 16);
     }
-    dt->lut2[idx] = ent;
+    s_lut2[idx] = ent;
   }
+  __syncthreads();
+  dec_image_fill(dt, s_lut, s_lut2, lb, pb, tid, 256);
 }
 
 // .crs: the same direct table, filled by walking the tree DecodeHuffTree::do_build_tree would rebuild
@@ -123,6 +145,7 @@ __global__ __launch_bounds__(256) void k_crs_decode_tables(const ghf_tree* __res
                                                            int* __restrict__ status) {
   __shared__ uint16_t tl[256], tr[256];
   __shared__ uint32_t s_min;
+  __shared__ uint16_t s_lut[1 << kDecLutBitsMax];
   const int tid = threadIdx.x;
   const int max_len = (int)tree->max_len;
   const uint32_t root = tree->root, nl = tree->n_leaves;
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(256) void k_crs_decode_tables(const ghf_tree* __res
         break;
       }
     }
-    dt->lut[idx] = ent;
+    s_lut[idx] = ent;
   }
   atomicMin(&s_min, mn);
   __syncthreads();
@@ -168,7 +191,9 @@ __global__ __launch_bounds__(256) void k_crs_decode_tables(const ghf_tree* __res
     dt->pair_bits = 0;
     dt->kind = 1;
     dt->root = root;
+    dt->done = 0;
   }
+  dec_image_fill(dt, s_lut, nullptr, lb, 0, tid, 256);
 }
 
 void launch_crs_decode_tables(const ghf_tree* d_tree, DecTables* d_dt, int* d_status, hipStream_t s) {
@@ -190,9 +215,6 @@ void launch_build_decode_tables(const ghf_code* d_code, DecTables* d_dt, int* d_
 // then, serves as the transposition buffer for the coalesced copy-out.
 constexpr int kDec7Threads = 1024;
 constexpr int kDec7Waves = kDec7Threads / kWave;
-constexpr int kDec7LutLog2 = 14;
-constexpr int kDec7LutSlots = 1 << kDec7LutLog2;
-constexpr int kDec7SmallSlots = 1024;  // pair mode (max_len <= 5): the one-symbol table for ragged tails and the end mark, 32 copies
 constexpr int kDec7InBytes = 4608;  // staged span per wave: 4096 symbols at <= 9 bits average (a byte-Huffman code averages <= 8.1)
 constexpr int kDec7InWords = kDec7InBytes / 4;
 // The input tiles are PADDED: 16 bytes after every 128.  A lane's segment of uniform bytes is ~64 bytes long, so the 32
@@ -204,7 +226,6 @@ constexpr int kDec7TileLog = kDec7InBytes + 128;                  // logical byt
 constexpr int kDec7TilePhys = kDec7TileLog / 128 * 144;           // 5328
 static_assert(kDec7TileLog % 128 == 0 && kDec7TilePhys >= 4096 + 16, "tile doubles as the 4 KiB transposition buffer");
 __device__ __forceinline__ uint32_t in_phys(uint32_t la) { return la + ((la >> 7) << 4); }
-constexpr uint32_t kEntEnd = 1u << 16, kEntNone = 1u << 17;
 struct DecLds7 {
   alignas(128) uint8_t in[kDec7Waves * kDec7TilePhys];  // compressed spans of the waves' groups, big-endian words, padded; then their output
   alignas(16) uint32_t lut[kDec7LutSlots + kDec7SmallSlots];
@@ -234,35 +255,12 @@ __device__ __forceinline__ void dec_small_load(LT& L, const DecTables* dt, int t
   }
 }
 
-__device__ __forceinline__ uint32_t dec7_entry(uint32_t g) {  // DecTables::lut entry (sym | len << 9) -> LDS entry
-  const uint32_t sym = g & 0x1FFu, len = g >> 9;
-  return (sym & 0xFFu) | (len << 8) | (sym == 256u ? kEntEnd : 0u) | (len == 0u ? kEntNone : 0u);
-}
-
-// replicated fill: one-symbol table, entry idx, copy r at lut[(idx << rlog) | r]; with a pair table (small alphabets)
-// the 64 KiB hold lut2 (two symbols per entry) and the one-symbol table goes into the small region behind it
+// the table image (DecTables::image, written by the table kernels in its final layout) and the small tables into LDS
 __device__ __forceinline__ void dec_lds_load7(DecLds7& L, const DecTables* dt, int tid, int nthreads) {
-  // (every table has at least four copies of an entry side by side: 16 bytes per store, a quarter of the round trips --
-  //  this prologue is paid by every launch of K7 and of the K6 kernels, several per file piece)
-  const int pb = dt->pair_bits, lb = dt->lut_bits;
+  constexpr int kVecs = (kDec7LutSlots + kDec7SmallSlots) / 4;
+  const uint4* const img4 = reinterpret_cast<const uint4*>(dt->image);
   uint4* const lut4 = reinterpret_cast<uint4*>(L.lut);
-  if (pb) {
-    const int r2 = (kDec7LutLog2 - pb) < 5 ? (kDec7LutLog2 - pb) : 5;
-    for (int g = tid; g < (1 << (pb + r2 - 2)); g += nthreads) {
-      const uint32_t e = dt->lut2[(4 * g) >> r2];
-      lut4[g] = make_uint4(e, e, e, e);
-    }
-    for (int g = tid; g < kDec7SmallSlots / 4; g += nthreads) {
-      const uint32_t e = dec7_entry(dt->lut[((4 * g) >> 5) & ((1 << lb) - 1)]);
-      lut4[kDec7LutSlots / 4 + g] = make_uint4(e, e, e, e);
-    }
-  } else {
-    const int r1 = (kDec7LutLog2 - lb) < 5 ? (kDec7LutLog2 - lb) : 5;
-    for (int g = tid; g < (1 << (lb + r1 - 2)); g += nthreads) {
-      const uint32_t e = dec7_entry(dt->lut[(4 * g) >> r1]);
-      lut4[g] = make_uint4(e, e, e, e);
-    }
-  }
+  for (int g = tid; g < kVecs; g += nthreads) lut4[g] = img4[g];
   dec_small_load(L, dt, tid, nthreads);
 }
 
@@ -356,18 +354,20 @@ __device__ __forceinline__ uint32_t dec_long_entry_at(const LT& L, uint64_t W, u
   }
 #define GHF_WINDOW_OPEN()                                              \
   uint32_t la = la0 + ((pos >> 5) << 2);                               \
-  const uint32_t la_first = la;                                        \
   uint32_t o = pos & 31u;                                              \
-  const uint32_t o0 = o;                                               \
   uint64_t W = ((uint64_t)in_word(lin, la) << 32) | in_word(lin, la + 4u); \
   uint32_t nextw = in_word(lin, la + 8u);                              \
   la += 12u
-#define GHF_WINDOW_USED() ((la - la_first - 12u) * 8u + o - o0)
+#define GHF_WINDOW_USED() ((la - la0 - 12u) * 8u + o - pos)  // (la - la_first - 12) * 8 + o - o0, la_first and o0 being pos's two halves
 
-// HOT: the 64 symbols of a full, staged segment whose codes all fit the direct table.  Straight-line code; the 64 bytes
-// stay in registers.  Returns the OR of all entries (kEntEnd / kEntNone set: not 64 data symbols -> corrupt).
-template <int K>
-__device__ __forceinline__ uint32_t dec_hot(const uint8_t* lin, uint32_t la0, const DecLut& T, uint32_t pos, uint32_t (&out)[16], uint32_t& used) {
+// HOT: the 64 symbols of a full, staged segment.  Straight-line code; the 64 bytes stay in registers.  LONG: codes beyond the
+// direct table exist (max_len > 12: Zipf 1.1 over 256 values has 13..14-bit codes for its rarest ones and the end mark at
+// 256 MiB) and take the reference's linear extension on a miss.  Returns the OR of all entries (kEntEnd / kEntNone set: not
+// 64 data symbols -> corrupt).  Every variant ends in the same four stores (the callers' copy-out), so that the compiler can
+// count the kernel's memory operations whichever variant runs.
+template <int K, bool LONG, typename LT>
+__device__ __forceinline__ uint32_t dec_hot(const LT& L, const uint8_t* lin, uint32_t la0, const DecLut& T, int lut_bits, int max_len, uint32_t pos,
+                                            uint32_t (&out)[16], uint32_t& used) {
   GHF_WINDOW_OPEN();
   uint32_t acc = 0;
 #pragma unroll
@@ -376,7 +376,9 @@ __device__ __forceinline__ uint32_t dec_hot(const uint8_t* lin, uint32_t la0, co
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if ((4 * d + j) % K == 0) GHF_REFILL();
-      const uint32_t ent = dec_lookup(T, (uint32_t)((W << o) >> 32));
+      const uint32_t v = (uint32_t)((W << o) >> 32);
+      uint32_t ent = dec_lookup(T, v);
+      if (LONG && __builtin_expect((ent & kEntNone) != 0, 0)) ent = dec_long_entry(L, v, lut_bits, max_len);
       o += (ent >> 8) & 0xFFu;
       e[j] = ent;
     }
@@ -385,6 +387,9 @@ __device__ __forceinline__ uint32_t dec_hot(const uint8_t* lin, uint32_t la0, co
     const uint32_t lo = __builtin_amdgcn_perm(e[1], e[0], 0x0C0C0400u);
     const uint32_t hi = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0400u);
     out[d] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+    // pack HERE: left alone, the scheduler sinks these five instructions behind the last lookup and keeps all 64 raw entries
+    // alive until then -- 64 registers instead of 16, which is what pushed round 3's kernel over its 128 and into scratch
+    __builtin_amdgcn_sched_barrier(0);
   }
   used = GHF_WINDOW_USED();
   return acc;
@@ -408,40 +413,60 @@ __device__ __forceinline__ uint32_t dec_hot_pair(const uint8_t* lin, uint32_t la
     }
     acc |= e[0] | e[1];
     out[d] = __builtin_amdgcn_perm(e[1], e[0], 0x05040100u);  // {a.sym0, a.sym1, b.sym0, b.sym1}
+    __builtin_amdgcn_sched_barrier(0);  // (as in dec_hot: pack now, do not keep the raw entries)
   }
   used = GHF_WINDOW_USED();
   return acc;
 }
 
-// HOT for codes beyond the direct table (max_len > 12: Zipf 1.1 over 256 values has 13..14-bit codes for its rarest ones
-// and the end mark): the reference's linear extension on a miss, sixteen output bytes per store, straight to memory (the
-// callers' out is 16-byte aligned on this path).
+// HOT, codes of (at most) TWO lengths L and L + 1 -- bytes that do not compress: 255 codes of 8 bits, two of 9.  Which of the
+// two a code has is one comparison of the next bits with the first L-bit code (canonical codes: the longer ones are the
+// numerically smaller ones, canonical_huff_encoder.cc:446-450), so the serial chain of a lane is shift -> compare -> add-with-
+// carry on REGISTERS -- 3 instructions, ~35 cycles with four waves on the SIMD -- and the table lookups hang off it instead of
+// being its links (with the lookup in the chain a symbol took 138 cycles, 57 of them the LDS round trip alone:
+// profiles/r04/k7_timeline_*.json, valu_lat.txt).  The refill is branch-free (a lane that needs no new word re-reads the one it
+// has), so the 64 symbols are ONE basic block; entries are packed one dword behind the lookups that fetch them.
 template <int K>
-__device__ __forceinline__ uint32_t dec_hot_long(const DecLds7& L, const uint8_t* lin, uint32_t la0, const DecLut& T, int lut_bits, int max_len,
-                                                 uint32_t pos, uint8_t* optr, uint32_t& used) {
-  GHF_WINDOW_OPEN();
+__device__ __forceinline__ uint32_t dec_hot_two(const uint8_t* lin, uint32_t la0, const DecLut& T, uint32_t thr, uint32_t lmin, uint32_t pos,
+                                                uint32_t (&out)[16], uint32_t& used) {
+  uint32_t la = la0 + ((pos >> 5) << 2);
+  uint32_t o = pos & 31u;
+  uint32_t hi = in_word(lin, la), lo = in_word(lin, la + 4u), nx = in_word(lin, la + 8u);
+  la += 8u;  // nx is the word at la
   uint32_t acc = 0;
-#pragma unroll 1
-  for (int q = 0; q < 4; ++q) {  // sixteen symbols = one 16-byte store (a quarter of the store instructions of one dword each)
-    uint32_t w[4] = {0, 0, 0, 0};
+  uint32_t e[4] = {0, 0, 0, 0}, p[4];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
+  for (int d = 0; d <= 16; ++d) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = e[j];
+    if (d < 16) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (j % K == 0) GHF_REFILL();
-        const uint32_t v = (uint32_t)((W << o) >> 32);
-        uint32_t ent = dec_lookup(T, v);
-        if (__builtin_expect((ent & kEntNone) != 0, 0)) ent = dec_long_entry(L, v, lut_bits, max_len);
-        o += (ent >> 8) & 0xFFu;
-        acc |= ent;
-        w[d] |= (ent & 0xFFu) << (8 * j);
+        if ((4 * d + j) % K == 0) {  // o <= 31 behind this, o + K * (L + 1) <= 63 before the next one
+          const bool mv = o >= 32u;
+          hi = mv ? lo : hi;
+          lo = mv ? nx : lo;
+          la += mv ? 4u : 0u;
+          o &= 31u;
+          nx = in_word(lin, la);  // (needed one refill from now)
+        }
+        const uint32_t v = (uint32_t)(((((uint64_t)hi << 32) | lo) << o) >> 32);
+        e[j] = dec_lookup(T, v);
+        o += lmin + (v < thr ? 1u : 0u);
       }
     }
-    reinterpret_cast<uint4*>(optr)[q] = make_uint4(w[0], w[1], w[2], w[3]);
+    if (d > 0) {
+      acc |= p[0] | p[1] | p[2] | p[3];
+      const uint32_t l2 = __builtin_amdgcn_perm(p[1], p[0], 0x0C0C0400u);
+      const uint32_t h2 = __builtin_amdgcn_perm(p[3], p[2], 0x0C0C0400u);
+      out[d - 1] = __builtin_amdgcn_perm(h2, l2, 0x05040100u);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (as in dec_hot: pack now, do not collect raw entries)
   }
-  used = GHF_WINDOW_USED();
+  used = (la - la0 - 8u) * 8u + o - pos;
   return acc;
 }
+
 #undef GHF_REFILL
 #undef GHF_WINDOW_OPEN
 #undef GHF_WINDOW_USED
@@ -493,166 +518,214 @@ __device__ __forceinline__ uint32_t dec_cold(const DecLds7& L, const DecIn<STAGE
 //   2. every lane decodes its 64 symbols from a 64-bit window: one LDS table lookup per symbol, the 64 bytes stay in
 //      registers;
 //   3. the wave's 4 KiB of output go through the (now dead) input tile and leave as four coalesced 1 KiB stores.
-// The loop is software-pipelined over groups so that no HBM latency is exposed: while group i is decoded,
-// the span of group i+1 is in flight into registers and the side-car entries of group i+2 are in flight too.
-struct DecMeta {   // side-car words of one group, as loaded: issued a whole pass before they are combined, and nothing in
-  uint64_t blk;    // between may need their values (a dependent use right behind the loads would make the compiler wait
-  uint32_t end;    // for every older memory operation, including the span prefetch).  blk = block start (same word in
-};                 // every lane), end = where MY segment ends, relative to blk
-
-struct DecGroup {  // one group, ready to be decoded
-  uint64_t byte0;  // uniform: first staged byte (16-aligned)
-  uint32_t span;   // uniform: staged bytes
-  uint32_t pos;    // bit of the staged span at which my segment starts
-  uint32_t expect; // bits of my segment
-  bool bad;        // my side-car words are implausible
+// The loop is software-pipelined over groups so that no HBM latency is exposed and nothing but the copy into LDS stands
+// between the arrival of a span and the request for the next one: while group i is decoded, the span of group i+1 is in
+// flight into registers, the descriptor of group i+1 (where to load, where every lane starts) was computed a pass earlier,
+// the side-car words of group i+2 are in flight, the number of group i+3 is known and the ticket for group i+4 is in flight.
+//
+// Round 3's form of this loop computed the next group's descriptor between the copy into LDS and the loads, held six
+// instantiations of the whole loop nest (one per decoder variant, each with its own cold path) and was spilled by the
+// register allocator INSIDE the hot loop of the variants uniform bytes take: the fifth vector of the prefetch went to
+// scratch right behind its load, i.e. behind an s_waitcnt vmcnt(0) -- every pass waited for the whole prefetch before it
+// decoded a symbol, the loads never overlapped the decode (profiles/r04/k7_spill_r03.txt has the listing).  Now: ONE loop,
+// the variant is a switch around the 64 lookups only, one cold path, and a CPU-side guard keeps the kernel scratch-free
+// (tests/test_cabi_cpu.py).
+struct DecMeta {   // side-car words of one group, as loaded: issued a whole pass before they are combined
+  uint64_t blk;    // block start (same word in every lane)
+  uint32_t end;    // where MY segment ends, relative to blk
 };
 
-__device__ __forceinline__ void dec_issue_meta(const DecParams& P, uint64_t group, int lane, DecMeta& M) {
-  const uint64_t last = P.n_segs - 1;
-  const uint64_t seg = group * 64 + lane;
+constexpr uint32_t kDecBadSeg = 0xFFFFFFFFu;
+struct DecGroup {       // one group, ready to be fetched and decoded
+  const uint8_t* base;  // uniform: what the span loads are relative to (the span's first byte, 16-aligned)
+  uint32_t lim;         // uniform: the vector at byte offset o of the span is loaded iff o + 16 <= lim
+  uint64_t byte0;       // uniform: first staged byte (16-aligned)
+  uint32_t span;        // uniform: staged bytes
+  uint32_t pos;         // bit of the staged span at which my segment starts
+  uint32_t expect;      // bits of my segment; kDecBadSeg: my side-car words are implausible (no decode consumes that many bits)
+  bool hot;             // uniform: complete, staged, plausible, not the stream's last group
+};
+
+struct DecConst {  // wave-uniform facts of one launch
+  uint64_t n_segs, stream_bytes, stream_end_bit, full_bytes;
+  uint32_t ngroups;
+  int max_len;
+  bool hot_ok;  // the output is 16-byte aligned and no code is longer than 32 bits
+};
+
+__device__ __forceinline__ void dec_issue_meta(const DecParams& P, const DecConst& C, uint32_t group, int lane, DecMeta& M) {
+  const uint64_t last = C.n_segs - 1;
+  const uint64_t seg = (uint64_t)group * 64 + lane;
   M.blk = P.chunk_bit[group];
   M.end = P.seg_bit[seg < last ? seg : last];  // clamped: unconditional loads
 }
 
-__device__ __forceinline__ void dec_group(const DecParams& P, uint64_t group, int lane, int max_len, const DecMeta& M, DecGroup& G) {
-  const uint64_t stream_end_bit = P.stream_bytes * 8;
-  const uint64_t seg0 = group * 64;
-  const bool valid = seg0 + lane < P.n_segs;
+__device__ __forceinline__ void dec_group(const DecParams& P, const DecConst& C, uint32_t group, int lane, const DecMeta& M, DecGroup& G) {
+  const uint64_t seg0 = (uint64_t)group * 64;
+  const bool valid = seg0 + lane < C.n_segs;
   const uint64_t B0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(M.blk >> 32)) << 32) |
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)M.blk);
   // my segment starts where my left neighbour's ends (v_mov_dpp wave_shr:1; lane 0 starts with the block)
   const uint32_t start = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)M.end, 0x138, 0xF, 0xF, true);
   uint64_t B1 = B0 + (uint32_t)__builtin_amdgcn_readlane((int)M.end, 63);
-  if (seg0 + 64 >= P.n_segs) {
-    // last group: bound it by its last segment's worst case (+ end mark) rather than by a side-car word
-    uint32_t m = valid ? start + 65u * (uint32_t)max_len : 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const uint32_t o = __shfl_xor(m, d, 64);
-      m = o > m ? o : m;
-    }
-    B1 = B0 + (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+  const bool last_group = seg0 + 64 >= C.n_segs;
+  if (last_group) {
+    // last group: bound it by its last segment's worst case (+ end mark) rather than by a side-car word.  Segment starts
+    // grow with the lane (a side-car that says otherwise is caught by `bad`), so the last valid lane's start is the largest
+    const uint32_t lastv = (uint32_t)(C.n_segs - 1 - seg0) & 63u;
+    B1 = B0 + (uint32_t)__builtin_amdgcn_readlane((int)start, (int)lastv) + 65u * (uint32_t)C.max_len;
   }
-  if (B1 > stream_end_bit) B1 = stream_end_bit;
+  if (B1 > C.stream_end_bit) B1 = C.stream_end_bit;
   G.byte0 = (B0 >> 3) & ~15ull;
   uint64_t byte1 = ((B1 + 7) >> 3) + 12;  // window look-ahead
-  if (byte1 > P.stream_bytes) byte1 = P.stream_bytes;
+  if (byte1 > C.stream_bytes) byte1 = C.stream_bytes;
   if (G.byte0 > byte1) G.byte0 = byte1 & ~15ull;  // corrupt side-car: caught by `bad`
   const uint64_t span = byte1 - G.byte0;
   G.span = span > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)span;
   G.pos = (uint32_t)(B0 & 127u) + start;
-  G.expect = M.end - start;
-  G.bad = valid && (M.end < start || B0 + M.end > stream_end_bit || B0 >= stream_end_bit);
+  const bool bad = valid && (M.end < start || B0 + M.end > C.stream_end_bit || B0 >= C.stream_end_bit);
+  G.expect = bad ? kDecBadSeg : M.end - start;
+  // vector k of a lane = bytes byte0 + k * 1024 + lane * 16 .. of the stream; it is loaded when it begins inside the span
+  // and ends inside the stream's whole 16-byte vectors:  o + 16 <= lim  <=>  o < span && byte0 + o + 16 <= full_bytes
+  uint32_t lim = 0;
+  if (G.byte0 <= C.full_bytes) {
+    const uint64_t room = C.full_bytes - G.byte0;
+    const uint64_t a = (uint64_t)G.span + 15u;
+    lim = (uint32_t)(a < room ? a : (room > 0x7FFFFFFFull ? 0x7FFFFFFFull : room));
+  }
+  G.lim = lim;
+  G.base = P.stream + (lim ? G.byte0 : 0ull);
+  G.hot = C.hot_ok && !last_group && G.span <= (uint32_t)kDec7InBytes && G.byte0 + G.span <= C.full_bytes && __ballot(bad) == 0;
+}
+
+// latch_status whose operands are materialised where it stands (the optimiser otherwise builds the compare-and-swap's
+// register pair in front of the loop and keeps it alive -- in scratch -- across all of it)
+__device__ __forceinline__ void latch_status_here(int* st, int code) {
+  int want = 0;
+  asm volatile("" : "+v"(code), "+v"(want));
+  atomicCAS(st, want, code);
 }
 
 constexpr int kDecVec = (kDec7InBytes + 1023) / 1024;  // 16-byte vectors per lane that cover a staged span
+constexpr int kDecStatic = 4;                           // groups every wave owns without asking (its pipeline depth)
 
-__global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
+__global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
   __shared__ DecLds7 L;
   const int tid = threadIdx.x;
-  if (tid == 0) L.status0 = *P.status;  // one read per workgroup: the exit must be uniform
-  __syncthreads();
-  if (L.status0 != 0) return;
-  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
-  const int pair_bits = P.dt->pair_bits;
   const int lane = tid & 63;
-  // this lane's replicas: T1 = one symbol per lookup, T2 = two (small alphabets only)
-  DecLut T1, T2;
-  {
-    const int r1 = pair_bits ? 5 : ((kDec7LutLog2 - lut_bits) < 5 ? (kDec7LutLog2 - lut_bits) : 5);
-    const uint32_t* t1 = L.lut + (pair_bits ? kDec7LutSlots : 0);
-    T1.base = reinterpret_cast<const char*>(t1 + ((uint32_t)lane & ((1u << r1) - 1u)));
-    T1.lsh = 32 - lut_bits;
-    T1.ash = r1 + 2;
-    const int r2 = (kDec7LutLog2 - pair_bits) < 5 ? (kDec7LutLog2 - pair_bits) : 5;
-    T2.base = reinterpret_cast<const char*>(L.lut + ((uint32_t)lane & ((1u << r2) - 1u)));
-    T2.lsh = 32 - pair_bits;
-    T2.ash = r2 + 2;
-  }
-  if (blockIdx.x == 0 && tid == 0 && P.out_bytes) *P.out_bytes = P.n_symbols;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar loop control
+  DecConst C;
+  C.n_segs = P.n_segs;
+  C.stream_bytes = P.stream_bytes;
+  C.stream_end_bit = P.stream_bytes * 8;
+  C.full_bytes = P.stream_bytes & ~15ull;  // whole 16-byte vectors of the stream
   // (group numbers are 32-bit -- launch_decode refuses more -- so that the loop control is scalar compares of single
-  //  registers: gfx9 has no scalar 64-bit ordering compare, and a uniform 64-bit bound kept in a VGPR pair was the one value
-  //  the allocator spilled inside the hot loops)
-  const uint32_t ngroups = (uint32_t)((P.n_segs + 63) >> 6);
-  const uint64_t full_bytes = P.stream_bytes & ~15ull;  // whole 16-byte vectors of the stream
-  const bool out_aligned = (((uintptr_t)P.out) & 15u) == 0;
-  const uint8_t* const lin = L.in;
-  const uint32_t la0 = (uint32_t)wave * kDec7TileLog;             // this wave's tile in the logical (unpadded) byte space
-  uint32_t* const tile = reinterpret_cast<uint32_t*>(L.in + (uint32_t)wave * kDec7TilePhys);  // ... and as plain memory (copy-out)
-  uint32_t bad_acc = 0;
-  // groups are handed out by a global ticket counter, not by a fixed stride: a wave that starts late (e.g. because
-  // another kernel occupied its CU) simply takes fewer groups instead of becoming the kernel's straggler
-  const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;  // every class needs at least one workgroup
-  const uint32_t cls = blockIdx.x % ncls;
-  auto ticket_issue = [&]() -> unsigned int {  // the atomic's return value stays in a VGPR until ticket_group() needs it
-    unsigned int t = 0;
-    if (lane == 0) t = atomicAdd(&P.dt->ticket[cls * 32], 1u);
-    return t;
-  };
-  // every wave's first three groups are fixed (no round trip to a counter before the first load can be issued: three
-  // dependent atomics on 16 counters cost the 4096 waves several microseconds of start-up); tickets number the rest
+  //  registers: gfx9 has no scalar 64-bit ordering compare)
+  C.ngroups = (uint32_t)((P.n_segs + 63) >> 6);
+  const uint32_t ngroups = C.ngroups, glast = ngroups - 1;
+  auto clampg = [&](uint32_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
+  // Groups.  Every wave owns its first kDecStatic groups and, by stride, its share of the first `nstat` rounds; the rest is
+  // handed out by ticket counters, so that a workgroup that starts late (another kernel occupied its CU) or runs slowly
+  // takes fewer groups instead of becoming the launch's straggler.  16 classes of workgroups, one counter each on its own
+  // 128-byte line (one word saturates at ~88 tickets per microsecond); class c owns the ticketed groups == c (mod 16).
   const uint32_t nwaves = gridDim.x * kDec7Waves;
   const uint32_t wid = blockIdx.x * kDec7Waves + (uint32_t)wave;
-  auto ticket_group = [&](unsigned int t) -> uint32_t {  // (saturating: a number past the end stays past the end)
-    const uint64_t g = 3ull * nwaves + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * ncls + cls;
+  const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;  // every class needs at least one workgroup
+  const uint32_t cls = blockIdx.x % ncls;
+  uint32_t nstat = (uint32_t)((uint64_t)(ngroups / nwaves) * P.static_permille / 1000u);
+  if (nstat < (uint32_t)kDecStatic) nstat = kDecStatic;
+  uint32_t claims = kDecStatic;  // groups this wave has asked for so far
+  uint32_t* const my_ticket = &P.dt->ticket[cls * 32];
+  auto claim_issue = [&]() -> unsigned int {  // the atomic's return value stays in a VGPR until claim_group() needs it, a pass later
+    unsigned int t = 0;
+    if (claims >= nstat && lane == 0) t = atomicAdd(my_ticket, 1u);
+    ++claims;
+    return t;
+  };
+  auto claim_group = [&](unsigned int t) -> uint32_t {  // the group of the claim issued last (saturating: past the end stays past the end)
+    const uint32_t c = claims - 1;
+    const uint64_t g = c < nstat ? (uint64_t)wid + (uint64_t)c * nwaves
+                                 : (uint64_t)nstat * nwaves + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * ncls + cls;
     return g < 0xFFFFFFFFull ? (uint32_t)g : 0xFFFFFFFFu;
   };
-  uint32_t group = wid;
-  uint32_t g1 = wid + nwaves, g2 = wid + 2 * nwaves;  // this wave's next two groups
-  const uint32_t glast = ngroups - 1;
-  auto clampg = [&](uint32_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
+  uint32_t g0 = wid, g1 = wid + nwaves, g2 = wid + 2 * nwaves, g3 = wid + 3 * nwaves;
 
-  // vector k of a lane = bytes byte0 + k*1024 + lane*16 .. of the stream; it is loaded when it begins inside the span
-  // and ends inside the stream's whole 16-byte vectors
-  auto vec_lim = [&](const DecGroup& G) -> uint32_t {  // wave-uniform: o + 16 <= lim  <=>  o < span && byte0 + o + 16 <= full_bytes
-    if (G.byte0 > full_bytes) return 0u;
-    const uint64_t room = full_bytes - G.byte0;
-    const uint64_t a = (uint64_t)G.span + 15u;
-    return (uint32_t)(a < room ? a : (room > 0x7FFFFFFFull ? 0x7FFFFFFFull : room));
-  };
-  auto vec_ok = [&](const DecGroup& G, int k, int lane) -> bool {
-    return (uint32_t)k * 1024u + (uint32_t)lane * 16u + 16u <= vec_lim(G);
-  };
-  auto issue = [&](const DecGroup& G, uint4 (&R)[kDecVec], int lane) {
-    const uint32_t lim = vec_lim(G);
-    const uint8_t* base = P.stream + (lim ? G.byte0 : 0ull);  // uniform
-#pragma unroll
-    for (int k = 0; k < kDecVec; ++k) {  // lanes behind the span re-read the span's first bytes (an L2 hit)
-      const uint32_t o = (uint32_t)k * 1024u + (uint32_t)lane * 16u;
-      R[k] = load_stream(base + (o + 16u <= lim ? o : 0u));  // read once: not worth a line of the Infinity Cache
-    }
-  };
-
-  // The first group's side-car words are requested BEFORE the table is built: one of the two dependent memory round trips
-  // in front of the first decode then hides behind the ~3 us of table replication.  (The span loads do not: 20 more
-  // registers alive across six loop nests made the allocator spill in all of them.)
-  DecMeta M;  // raw side-car words of the group after `cur` (of the one after that once the pass has issued its loads)
-  const bool mine = group < ngroups;
-  if (mine) dec_issue_meta(P, group, lane, M);
+  // The first two groups' side-car words are requested BEFORE the tables are pulled in: one of the dependent memory round
+  // trips in front of the first decode hides behind the table copy.
+  DecMeta M0, M;
+  dec_issue_meta(P, C, clampg(g0), lane, M0);
+  dec_issue_meta(P, C, clampg(g1), lane, M);
+  if (tid == 0) L.status0 = *P.status;  // one read per workgroup: whether the launch does anything must be uniform
+  const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
+  const int pair_bits = P.dt->pair_bits;
   dec_lds_load7(L, P.dt, tid, kDec7Threads);
+  if (blockIdx.x == 0 && tid == 0 && P.out_bytes) *P.out_bytes = P.n_symbols;
   __syncthreads();
-  if (!mine) return;
+  C.max_len = max_len;
+  C.hot_ok = (((uintptr_t)P.out) & 15u) == 0 && max_len <= 32;  // codes beyond 32 bits (a very deep .crs tree): one symbol at a time
 
-  // one instantiation of the whole loop per decoder variant: the hot pass then holds ONE straight-line decoder
-  auto run = [&](auto var_tag) {
+  if (L.status0 == 0 && g0 < ngroups) {
+    // a lane's replicas of the tables: T1 = one symbol per lookup, T2 = two (small alphabets only).  The uniform parts live in
+    // SGPRs, the lane's part is recomputed in every pass (two VALU instructions instead of two registers)
+    const int r1 = pair_bits ? 5 : ((kDec7LutLog2 - lut_bits) < 5 ? (kDec7LutLog2 - lut_bits) : 5);
+    const int r2 = (kDec7LutLog2 - pair_bits) < 5 ? (kDec7LutLog2 - pair_bits) : 5;
+    const uint32_t* const t1 = L.lut + (pair_bits ? kDec7LutSlots : 0);
+    auto lut1 = [&](int ln) {
+      DecLut T;
+      T.base = reinterpret_cast<const char*>(t1 + ((uint32_t)ln & ((1u << r1) - 1u)));
+      T.lsh = 32 - lut_bits;
+      T.ash = r1 + 2;
+      return T;
+    };
+    auto lut2 = [&](int ln) {
+      DecLut T;
+      T.base = reinterpret_cast<const char*>(L.lut + ((uint32_t)ln & ((1u << r2) - 1u)));
+      T.lsh = 32 - pair_bits;
+      T.ash = r2 + 2;
+      return T;
+    };
+    // decoder variant (wave-uniform): 0 pair table; 1..3 K = 4 / 3 / 2 symbols per refill check; 4, 5 codes beyond the table
+    // K = 32 / max_len symbols per refill check (o <= 31 behind a check, o + K * max_len <= 63 before the next: a single
+    // refill brings it back below 32.  With 33 -- max_len 11, K = 3 -- o could reach 64, stay at 32 behind the refill, and
+    // the third lookup of the next round would read past the window: six 11-bit codes in a row at the right phase, found by
+    // scratch/host_soak.py)
+    // 6..8: canonical codes of at most two lengths that the table resolves (max_len 6..8 / 9, 10 / 11, 12): the length chain runs
+    // on registers (dec_hot_two), K = 4 / 3 / 2
+    const int min_len = P.dt->min_len;
+    const bool two = P.dt->kind == 0 && !pair_bits && max_len - min_len <= 1 && max_len <= kDecLutBitsMax && max_len >= 6;
+    const uint32_t two_thr = max_len > min_len ? P.dt->fc_left[min_len & 31] : 0u;
+    const int var = two ? (max_len <= 8 ? 6 : max_len <= 10 ? 7 : 8)
+                        : pair_bits ? 0 : max_len <= 8 ? 1 : max_len <= 10 ? 2 : max_len <= kDecLutBitsMax ? 3 : max_len <= 16 ? 4 : 5;
+    const uint8_t* const lin = L.in;
+    const uint32_t la0 = (uint32_t)wave * kDec7TileLog;             // this wave's tile in the logical (unpadded) byte space
+    uint32_t* const tile = reinterpret_cast<uint32_t*>(L.in + (uint32_t)wave * kDec7TilePhys);  // ... and as plain memory (copy-out)
+    uint32_t bad_acc = 0;
+
+    auto issue = [&](const DecGroup& G, uint4 (&R)[kDecVec], int ln) {
+#pragma unroll
+      for (int k = 0; k < kDecVec; ++k) {  // lanes behind the span re-read the span's first bytes (an L2 hit)
+        const uint32_t o = (uint32_t)k * 1024u + (uint32_t)ln * 16u;
+        R[k] = load_stream(G.base + (o + 16u <= G.lim ? o : 0u));  // read once: not worth a line of the Infinity Cache
+      }
+    };
+
     DecGroup cur, nxt;
     uint4 R[kDecVec];
-    dec_group(P, group, lane, max_len, M, cur);
+    dec_group(P, C, clampg(g0), lane, M0, cur);
     issue(cur, R, lane);
-    dec_issue_meta(P, clampg(g1), lane, M);
+    dec_group(P, C, clampg(g1), lane, M, nxt);
+    dec_issue_meta(P, C, clampg(g2), lane, M);
+    unsigned int tk = claim_issue();  // for the group after g3
 
     // One pass over a group.  HOT = the group is complete, staged, plausible and not the stream's last: the body then has
     // no data-dependent branch around its memory operations, so the compiler can count them -- the wait for the
-    // prefetched span becomes "all but the youngest four" (this group's output stores) instead of vmcnt(0), and the wave
-    // no longer sleeps until its own stores are acknowledged by L2 (which is what bounded this kernel in round 1).
-    auto pass = [&](auto hot_tag, auto var_tag) {
+    // prefetched span becomes "all but the youngest seven" (this group's output stores, the next side-car words, the
+    // ticket) instead of vmcnt(0), and the wave never sleeps until its own stores are acknowledged by L2.
+    auto pass = [&](auto hot_tag) {
       constexpr bool HOT = decltype(hot_tag)::value;
-      constexpr int VAR = decltype(var_tag)::value;
-      // the lane number, opaque to the optimiser: everything derived from it below (a dozen LDS and global addresses) is
-      // recomputed per pass with a few VALU instructions instead of being hoisted out of the loop and then spilled
-      int ln = lane;
+      // the lane number, recomputed (v_mbcnt) and opaque to the optimiser: everything derived from it below (a dozen LDS and
+      // global addresses) costs a few VALU instructions per pass instead of registers that live across the whole loop
+      int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       asm volatile("" : "+v"(ln));
       // ---- 1. this group's span: registers -> LDS (big-endian words).  HOT: whatever a lane loaded behind the span is
       // harmless (only a corrupt stream reads it, and that is caught by the segment-end check); else it reads as zero
@@ -662,115 +735,109 @@ __global__ __launch_bounds__(kDec7Threads, 4) void k_decode(DecParams P) {
         const uint32_t o = (uint32_t)k * 1024u + (uint32_t)ln * 16u;
         uint4 v = R[k];
         v = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
-        if (!HOT && !vec_ok(cur, k, ln)) v = make_uint4(0, 0, 0, 0);
+        if (!HOT && !(o + 16u <= cur.lim)) v = make_uint4(0, 0, 0, 0);
         if ((k + 1) * 1024 <= kDec7InBytes || o < (uint32_t)kDec7InBytes)
           *reinterpret_cast<uint4*>(L.in + in_phys(la0 + o)) = v;
       }
       if (ln < 4) *reinterpret_cast<uint32_t*>(L.in + in_phys(la0 + kDec7InBytes + 4u * ln)) = 0;
-      if (!HOT && cur.byte0 + cur.span > full_bytes && full_bytes >= cur.byte0 && ln == 0) {
+      if (!HOT && cur.byte0 + cur.span > C.full_bytes && C.full_bytes >= cur.byte0 && ln == 0) {
         // the stream's last, incomplete 16 bytes: byte loads, never past the end of the buffer
         uint32_t q[4] = {0, 0, 0, 0};
-        for (uint64_t j = 0; full_bytes + j < P.stream_bytes; ++j) q[j >> 2] |= (uint32_t)P.stream[full_bytes + j] << (24 - 8 * (j & 3));
-        const uint64_t w = (full_bytes - cur.byte0) >> 2;
+        for (uint64_t j = 0; C.full_bytes + j < C.stream_bytes; ++j) q[j >> 2] |= (uint32_t)P.stream[C.full_bytes + j] << (24 - 8 * (j & 3));
+        const uint64_t w = (C.full_bytes - cur.byte0) >> 2;
         if (w + 3 < (uint64_t)kDec7InWords + 4) {
           for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t*>(L.in + in_phys(la0 + 4u * (uint32_t)(w + j))) = q[j];
         }
       }
       wave_sync();
-      // ---- prefetch: span of the next group (its side-car entries arrived during the last decode), side-car of the one after
-      dec_group(P, clampg(g1), ln, max_len, M, nxt);
+      // ---- 2. the next group's span is requested at once: its descriptor was computed a pass ago
       issue(nxt, R, ln);
-      dec_issue_meta(P, clampg(g2), ln, M);
-      const unsigned int t3 = ticket_issue();  // resolved after the decode
-      // ---- 2. decode
-      const uint64_t seg0 = (uint64_t)group * 64;
+      // ---- 3. decode
+      const uint64_t seg0 = (uint64_t)g0 * 64;
       const uint64_t seg = seg0 + ln;
       const uint64_t sym0 = seg * kSegSymbols;
       if (HOT) {
         uint32_t used, acc;
-        if (VAR <= 3) {
-          uint32_t out[16];
-          // K = 32 / max_len symbols per refill check (o <= 31 behind a check, o + K * max_len <= 63 before the next: a
-          // single refill brings it back below 32.  With 33 -- max_len 11, K = 3 -- o could reach 64, stay at 32 behind the
-          // refill, and the third lookup of the next round would read past the window: six 11-bit codes in a row at the
-          // right phase, found by scratch/host_soak.py)
-          if (VAR == 0) acc = dec_hot_pair(lin, la0, T2, cur.pos, out, used) >> 14;  // bit 30 -> bit 16
-          else if (VAR == 1) acc = dec_hot<4>(lin, la0, T1, cur.pos, out, used);
-          else if (VAR == 2) acc = dec_hot<3>(lin, la0, T1, cur.pos, out, used);
-          else acc = dec_hot<2>(lin, la0, T1, cur.pos, out, used);
-          // ---- 3. copy-out through the input tile (dead now): ln-major 64-byte rows, pieces XOR-swizzled so that the 16
-          // lanes of a write phase hit 16 different bank groups; then four fully coalesced 1 KiB stores per wave,
-          // straight-line, so that the compiler can count them
-          wave_sync();
-          const uint32_t osw = ((uint32_t)ln >> 2) & 3u;
-  #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<uint4*>(tile + ln * 16 + (((uint32_t)q ^ osw) << 2)) = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
-          wave_sync();
-          uint8_t* og = P.out + seg0 * kSegSymbols + (uint32_t)ln * 16;
-  #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const uint32_t sl = (uint32_t)r * 16 + ((uint32_t)ln >> 2);  // the ln whose row holds my piece
-            const uint32_t piece = ((uint32_t)ln & 3u) ^ ((sl >> 2) & 3u);
-            store_stream(og + r * 1024, *reinterpret_cast<const uint4*>(tile + sl * 16 + piece * 4));
-          }
-        } else if (VAR == 4) {
-          acc = dec_hot_long<2>(L, lin, la0, T1, lut_bits, max_len, cur.pos, P.out + sym0, used);
-        } else {
-          acc = dec_hot_long<1>(L, lin, la0, T1, lut_bits, max_len, cur.pos, P.out + sym0, used);
+        uint32_t out[16];
+        if (var == 0) acc = dec_hot_pair(lin, la0, lut2(ln), cur.pos, out, used) >> 14;  // bit 30 -> bit 16
+        else if (var == 1) acc = dec_hot<4, false>(L, lin, la0, lut1(ln), lut_bits, max_len, cur.pos, out, used);
+        else if (var == 2) acc = dec_hot<3, false>(L, lin, la0, lut1(ln), lut_bits, max_len, cur.pos, out, used);
+        else if (var == 3) acc = dec_hot<2, false>(L, lin, la0, lut1(ln), lut_bits, max_len, cur.pos, out, used);
+        else if (var == 4) acc = dec_hot<2, true>(L, lin, la0, lut1(ln), lut_bits, max_len, cur.pos, out, used);
+        else if (var == 5) acc = dec_hot<1, true>(L, lin, la0, lut1(ln), lut_bits, max_len, cur.pos, out, used);
+        else if (var == 6) acc = dec_hot_two<4>(lin, la0, lut1(ln), two_thr, (uint32_t)min_len, cur.pos, out, used);
+        else if (var == 7) acc = dec_hot_two<3>(lin, la0, lut1(ln), two_thr, (uint32_t)min_len, cur.pos, out, used);
+        else acc = dec_hot_two<2>(lin, la0, lut1(ln), two_thr, (uint32_t)min_len, cur.pos, out, used);
+        // copy-out through the input tile (dead now): lane-major 64-byte rows, pieces XOR-swizzled so that the 16
+        // lanes of a write phase hit 16 different bank groups; then four fully coalesced 1 KiB stores per wave,
+        // straight-line, so that the compiler can count them
+        wave_sync();
+        const uint32_t osw = ((uint32_t)ln >> 2) & 3u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<uint4*>(tile + ln * 16 + (((uint32_t)q ^ osw) << 2)) = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+        wave_sync();
+        uint8_t* og = P.out + seg0 * kSegSymbols + (uint32_t)ln * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t sl = (uint32_t)r * 16 + ((uint32_t)ln >> 2);  // the lane whose row holds my piece
+          const uint32_t piece = ((uint32_t)ln & 3u) ^ ((sl >> 2) & 3u);
+          store_stream(og + r * 1024, *reinterpret_cast<const uint4*>(tile + sl * 16 + piece * 4));
         }
         if (used != cur.expect) acc |= kEntNone;
         bad_acc |= acc;
       } else {
-        const bool valid = seg < P.n_segs;
-        if (__ballot(cur.bad)) {
-          if (cur.bad) latch_status(P.status, GHF_E_CORRUPT);
+        const bool valid = seg < C.n_segs;
+        if (__ballot(cur.expect == kDecBadSeg)) {
+          if (cur.expect == kDecBadSeg) latch_status_here(P.status, GHF_E_CORRUPT);
         } else {
           const bool staged = cur.span <= (uint32_t)kDec7InBytes;
           uint32_t cnt = 0;
           if (valid) cnt = (P.n_symbols - sym0 >= (uint64_t)kSegSymbols) ? (uint32_t)kSegSymbols : (uint32_t)(P.n_symbols - sym0);
           // 1: the side-car says where the next segment starts; 0: the end mark must follow; 2: nothing to check
-          const int has_next = seg + 1 < P.n_segs ? 1 : (P.no_end_mark ? 2 : 0);
+          const int has_next = seg + 1 < C.n_segs ? 1 : (P.no_end_mark ? 2 : 0);
           const uint8_t* src = P.stream + cur.byte0;
           if (staged) {
             DecIn<true> I{lin, la0, src, cur.span};
-            bad_acc |= dec_cold<true>(L, I, T1, lut_bits, max_len, cur.pos, cnt, valid, P.out + sym0, has_next, cur.expect);
+            bad_acc |= dec_cold<true>(L, I, lut1(ln), lut_bits, max_len, cur.pos, cnt, valid, P.out + sym0, has_next, cur.expect);
           } else {
             DecIn<false> I{lin, la0, src, cur.span};
-            bad_acc |= dec_cold<false>(L, I, T1, lut_bits, max_len, cur.pos, cnt, valid, P.out + sym0, has_next, cur.expect);
+            bad_acc |= dec_cold<false>(L, I, lut1(ln), lut_bits, max_len, cur.pos, cnt, valid, P.out + sym0, has_next, cur.expect);
           }
         }
       }
-      // ---- rotate (all of these values have long arrived)
+      // ---- 4. behind the decode, where nothing waits for it: the descriptor of the group after the next (its side-car
+      // words were requested a pass ago), the side-car words of the one after that, the number of the one after that
       cur = nxt;
-      group = g1;
+      dec_group(P, C, clampg(g2), ln, M, nxt);
+      g0 = g1;
       g1 = g2;
-      g2 = ticket_group(t3);
+      g2 = g3;
+      g3 = claim_group(tk);
+      dec_issue_meta(P, C, clampg(g2), ln, M);
+      tk = claim_issue();
     };
-    auto is_hot = [&]() -> bool {  // wave-uniform
-      if (group + 1 >= ngroups || !out_aligned || max_len > 32) return false;  // the last group may be ragged / carries the end mark;
-                                                                                // codes beyond 32 bits (a very deep .crs tree): one symbol at a time
-      if (cur.span > (uint32_t)kDec7InBytes || cur.byte0 + cur.span > full_bytes) return false;
-      return __ballot(cur.bad) == 0;
-    };
-    while (group < ngroups) {
-      if (is_hot()) {
+    while (g0 < ngroups) {
+      if (cur.hot) {
         // drain once on entry: the hot loop's waits are then computed from its own back edge alone (exact counts)
         // instead of being merged with whatever the cold paths left outstanding
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        do pass(std::true_type{}, var_tag);
-        while (is_hot());
+        do pass(std::true_type{});
+        while (g0 < ngroups && cur.hot);
       }
-      if (group < ngroups) pass(std::false_type{}, var_tag);
+      if (g0 < ngroups) pass(std::false_type{});
     }
-  };
-  if (pair_bits) run(std::integral_constant<int, 0>{});
-  else if (max_len <= 8) run(std::integral_constant<int, 1>{});
-  else if (max_len <= 10) run(std::integral_constant<int, 2>{});
-  else if (max_len <= kDecLutBitsMax) run(std::integral_constant<int, 3>{});
-  else if (max_len <= 16) run(std::integral_constant<int, 4>{});
-  else run(std::integral_constant<int, 5>{});
-  if (bad_acc & (kEntEnd | kEntNone)) latch_status(P.status, GHF_E_CORRUPT);  // 64 data symbols per full segment, always
+    if (bad_acc & (kEntEnd | kEntNone)) latch_status_here(P.status, GHF_E_CORRUPT);  // 64 data symbols per full segment, always
+  }
+  // the last workgroup to finish hands the ticket counters back as it found them
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned int arrived = atomicAdd(&P.dt->done, 1u);
+    if (arrived == gridDim.x - 1) {
+      for (int k = 0; k < 16; ++k) __hip_atomic_store(&P.dt->ticket[k * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&P.dt->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 void launch_decode(const DecParams& p, hipStream_t s) {
@@ -778,7 +845,7 @@ void launch_decode(const DecParams& p, hipStream_t s) {
   uint64_t blocks = (groups + kDec7Waves - 1) / kDec7Waves;
   if (blocks == 0) return;
   if (groups >= kDecMaxGroups) return;  // (k_decode numbers its groups in 32 bits; the callers refuse such an index first)
-  if (blocks > 256) blocks = 256;  // persistent: one workgroup of 16 waves per CU (its LDS tiles + table take 146 KiB)
+  if (blocks > 256) blocks = 256;  // persistent: one workgroup of 16 waves per CU (its LDS tiles + table take 153 KiB)
   hipLaunchKernelGGL(k_decode, dim3((uint32_t)blocks), dim3(kDec7Threads), 0, s, p);
 }
 

@@ -37,6 +37,10 @@ constexpr int kStageCapBits = (kStageWords - 8) * 32;
 // K7 decode / K6 side-car reconstruction
 constexpr int kDecPairBitsMax = 10;
 constexpr int kDecLutBitsMax = 12;
+// K7 / K6 keep the direct table in LDS as 32-bit entries, replicated (ghf_decode.hip): 64 KiB of slots + a small region
+constexpr int kDec7LutLog2 = 14;
+constexpr int kDec7LutSlots = 1 << kDec7LutLog2;
+constexpr int kDec7SmallSlots = 1024;  // pair mode (max_len <= 5): the one-symbol table for ragged tails and the end mark, 32 copies
 
 inline uint32_t chunk_symbols_for(uint64_t n) {
   const uint64_t per_slot = (n + kEmitSlots - 1) / kEmitSlots;
@@ -66,10 +70,17 @@ struct DecTables {
   // a single counter made the 256 MiB decode 4.8x slower), so the workgroups are split into 16 classes
   // (blockIdx % 16), each with its own counter on its own 128-byte line; class c owns the groups == c (mod 16).
   uint32_t ticket[16 * 32];
-  uint16_t lut[1 << kDecLutBitsMax];  // sym | len << 9 ; 0 = code longer than lut_bits
-  // two symbols per lookup for small alphabets (max_len <= 5): index = next pair_bits stream bits,
-  // entry = sym0 | sym1 << 8 | (len0 + len1) << 16 ; bit 30 = not two data symbols (end mark / no such code)
-  uint32_t lut2[1 << kDecPairBitsMax];
+  // workgroups of the running k_decode that have finished; the last one zeroes the counters again (and this word), so
+  // that tables stay usable for any number of launches
+  uint32_t done;
+  // The direct table(s) exactly as K7 / K6 keep them in LDS (ghf_decode.hip: 32-bit entries, replicated): written once by the
+  // table kernels, pulled in by every workgroup with 16-byte loads (round 3 replicated a compact table in every workgroup's
+  // prologue: ~3 us per launch of K7 and of every K6 kernel).  One-symbol table: index = the next lut_bits stream bits,
+  //   entry = symbol | length << 8 | bit 16: end mark | bit 17: no code of <= lut_bits bits starts with these bits
+  // in min(32, 2^(14 - lut_bits)) copies, slot = index * copies + copy.  Small alphabets (pair_bits != 0): the first 2^14 slots
+  // hold the pair table -- index = the next pair_bits bits, entry = sym0 | sym1 << 8 | (len0 + len1) << 16 | bit 30: not two data
+  // symbols -- and the one-symbol table follows in 32 copies.
+  alignas(16) uint32_t image[kDec7LutSlots + kDec7SmallSlots];
 };
 
 struct EmitParams {
@@ -98,6 +109,7 @@ struct DecParams {
   uint64_t n_symbols;
   uint64_t n_segs;
   uint32_t no_end_mark;  // the last symbol is not followed by the end mark (a shard that is not the stream's last)
+  uint32_t static_permille;  // share of a wave's rounds it owns by stride before the ticket counters take over (0..1000)
   uint8_t* out;
   uint64_t* out_bytes;  // optional device u64 <- n_symbols
   int* status;

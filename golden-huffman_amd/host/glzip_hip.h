@@ -455,11 +455,17 @@ class Pipe {
     pre_fd_ = -1;
     if (!wants_map(bound)) return;
     size_t have = 0;  // GHF_SINK=reuse: what the file already holds counts as made pages (the caller's promise: no holes)
+    size_t size = 0;  // ... and its REAL size decides whether it has to grow: stores through a shared mapping behind the end of
+                      // the file are unspecified, also inside its last page (tmpfs keeps them, xfs / ext4 zero that tail when the
+                      // file is extended or written back) -- a new output 1..4095 bytes longer than the old one lands exactly there
     if (sink_reuses()) {
       struct stat st;
-      if (fstat(fd, &st) == 0 && st.st_size > 0) have = ((size_t)st.st_size + 4095) & ~(size_t)4095;  // (its last, partial page is a page)
+      if (fstat(fd, &st) == 0 && st.st_size > 0) {
+        size = (size_t)st.st_size;
+        have = (size + 4095) & ~(size_t)4095;  // (its last, partial page is a page)
+      }
     }
-    if (have < bound && ftruncate(fd, (off_t)bound) != 0) return;
+    if (size < bound && ftruncate(fd, (off_t)bound) != 0) return;
     sized_ = true;
     void* m = mmap(NULL, bound, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     if (m == MAP_FAILED) return;

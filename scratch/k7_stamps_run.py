@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""GPU side of the K7 timeline diagnostic (scratch/k7_stamps_build.py): one decode with the stamped library, then the
+per-wave accumulators from behind the decoded output.  Cycles are s_memtime ticks (shader clock).
+
+    python scratch/k7_stamps_run.py [mib] [kind]
+"""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, pkgload
+pkg = pkgload.load(); ghf = pkg.ghf
+ghf.LIB_PATH = os.path.join(ROOT, "scratch", "exp", os.environ.get("STAMP_LIB", "libghf_stamps.so"))
+from golden_huffman_amd import synth
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+kind = sys.argv[2] if len(sys.argv) > 2 else "uniform"
+ctx = ghf.Context(0)
+n = mib << 20
+d_in = synth.make(torch, kind, n, offset=0, device="cuda")
+out = ctx.empty_u8(ghf.compress_bound(n))
+dec = ctx.empty_u8(n + (4 << 20))
+idx = ctx.index_alloc(n)
+h = ctx.histogram(d_in); c = ctx.build_code(h); ctx.encode_plan(d_in, c)
+end = ctx.encode_emit(d_in, c, out, flags=ghf.EMIT_LAST | ghf.EMIT_HEADER, index=idx)
+torch.cuda.synchronize()
+nb = int(end[1].item())
+for _ in range(3):
+    ctx.decode_prepare(c); ctx.decode(out, nb, c, idx, d_out=dec)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize()
+ctx.decode_prepare(c)
+e0.record(); ctx.decode(out, nb, c, idx, d_out=dec); e1.record()
+ctx.sync(); torch.cuda.synchronize()
+assert bool((dec[:n] == d_in).all().item())
+off = (n + 255) & ~255
+w = dec[off:off + 4096 * 64].cpu().numpy().view("<u8").reshape(4096, 8).astype("float64")
+import numpy as np
+a, b, c_, d, np_, life, begin, endt = (w[:, i] for i in range(8))
+t0 = begin.min()
+print(json.dumps({
+    "mib": mib, "kind": kind, "decode_event_ms": round(e0.elapsed_time(e1), 4),
+    "passes_per_wave": [float(np_.min()), float(np_.mean()), float(np_.max())],
+    "per_pass_cycles": {"wait+stage+issue": round(float((a / np_).mean()), 1), "decode": round(float((b / np_).mean()), 1),
+                        "copy_out": round(float((c_ / np_).mean()), 1), "descr+meta+ticket": round(float((d / np_).mean()), 1)},
+    "wave_life_cycles": [float(life.min()), float(life.mean()), float(life.max())],
+    "first_start_to_last_end_cycles": float(endt.max() - t0), "start_spread_cycles": float(begin.max() - t0),
+    "end_spread_cycles": float(endt.max() - endt.min()),
+    "sum_stamped_over_life": round(float(((a + b + c_ + d) / life).mean()), 3)}))

@@ -340,3 +340,25 @@ def test_sink_reuse_writes_over_an_existing_output_file(tool, tmp_path):
         assert subprocess.run([tool, str(f) + ".crs2", "4"], timeout=300, env=env).returncode == 0
         back = np.fromfile(str(f) + ".crs2.de", dtype=np.uint8)
         assert back.size == data.size and np.array_equal(back, data)
+
+
+def test_sink_reuse_grows_inside_the_old_files_last_page(tool, tmp_path):
+    """GHF_SINK=reuse, the case between "larger" and "smaller": the new output is 1..4095 bytes longer than the old one and
+    ends in the old file's LAST page -- the sink must extend the file before it maps it (stores behind the end of a file
+    through a shared mapping are unspecified; tmpfs keeps them, xfs and ext4 zero them).  Decoded files (their size is the
+    exact bound) and compressed ones, sizes not page aligned."""
+    import datagen as dg
+
+    env = _env(GHF_SINK="reuse", GHF_IO_THREADS=4)
+    f = tmp_path / "y.bin"
+    base = (5 << 20) + 100  # 100 bytes into a page
+    for n in (base, base + 1, base + 700, base + 3995):  # ... every next one ends in the same last page as the one before
+        data = dg.uniform_bytes(n, seed=11)
+        data.tofile(f)
+        assert subprocess.run([tool, str(f), "3"], timeout=300, env=env).returncode == 0
+        crs = np.fromfile(str(f) + ".crs2", dtype=np.uint8)
+        ref = orc.compress(data)
+        assert crs.size == ref.size and np.array_equal(crs, ref), n
+        assert subprocess.run([tool, str(f) + ".crs2", "4"], timeout=300, env=env).returncode == 0
+        back = np.fromfile(str(f) + ".crs2.de", dtype=np.uint8)
+        assert back.size == n and np.array_equal(back, data), n

@@ -794,3 +794,59 @@ def test_histogram_exact_for_every_vector_count_remainder(env, mib):
     ctx.sync()
     lengths = torch.tensor(list(ctx.code_to_host(code).length)[:256], dtype=torch.int64, device="cuda")
     assert int(total.item()) == int((want * lengths).sum().item())
+
+
+def _big_cases():
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_big.json")
+    return json.load(open(path))["cases"]
+
+
+def _sha_device(torch, t, nbytes, piece=1 << 28):
+    h = hashlib.sha256()
+    for lo in range(0, nbytes, piece):
+        h.update(t[lo : min(lo + piece, nbytes)].cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("name", sorted(_big_cases()))
+def test_full_size_config_equals_the_compiled_reference(env, name):
+    """The BASELINE configs at FULL size against the reference itself (tests/golden/golden_big.json: ref_glzip on the same
+    seeded stream, tests/golden/make_golden_big.py): the .crs2 the GPU writes has the reference file's size, header bytes and
+    SHA-256 -- every byte of up to 4.3 GB -- and decodes back to the input, with the side-car and without it.  The flow is
+    compressor_func_test's (unit_tests/test.cc:48-84, 101-141) with the byte compare done through the digest."""
+    import base64
+    import importlib
+
+    ghf, ctx, torch = env
+    pkgload.load()
+    synth = importlib.import_module("golden_huffman_amd.synth")
+    rec = _big_cases()[name]
+    n = rec["n"]
+    d_in = synth.make(torch, rec["kind"], n, offset=rec["offset"], device="cuda")
+    assert _sha_device(torch, d_in, n) == rec["input_sha256"]  # synth.make (GPU) == tests/datagen.py (what the reference read)
+    idx = ctx.index_alloc(n)
+    out = ctx.empty_u8(ghf.compress_bound(n))
+    d_out, nbytes, d_code = ctx.compress(d_in, d_out=out, index=idx)
+    ctx.sync()
+    nb = int(nbytes.item())
+    assert nb == rec["crs2_bytes"]
+    hs = rec["header_bytes"]
+    assert d_out[:hs].cpu().numpy().tobytes() == base64.b64decode(rec["header_b64"])
+    assert _sha_device(torch, d_out, nb) == rec["crs2_sha256"]
+    back, nout = ctx.decode(d_out, nb, d_code, idx)
+    ctx.sync()
+    assert int(nout.item()) == n
+    for lo in range(0, n, 1 << 30):
+        assert bool((back[lo : lo + (1 << 30)] == d_in[lo : lo + (1 << 30)]).all().item()), lo
+    back.zero_()
+    back2, nout2 = ctx.decode(d_out, nb, d_code, None, d_out=back)  # no side-car: K6 rebuilds it (what a reference-written file needs)
+    ctx.sync()
+    assert int(nout2.item()) == n
+    for lo in range(0, n, 1 << 30):
+        assert bool((back2[lo : lo + (1 << 30)] == d_in[lo : lo + (1 << 30)]).all().item()), lo
+    ctx.index_free(idx)
+    del d_in, out, back, back2, d_out
+    torch.cuda.empty_cache()
