@@ -268,7 +268,8 @@ def main():
     bound = ghf.compress_bound(n) if world == 1 else ghf.shard_bound(n)
     # Buffer sets: steps in flight work on different inputs and write different outputs.  Set s of rank r is the byte range
     # [(s * world + r) * n, +n) of one long synthetic stream, so that (for every s) the ranks' shards are consecutive.
-    NSETS = max(1, int(os.environ.get("GHF_BENCH_SETS", "3" if os.environ.get("GHF_BENCH_MAINS", "1") == "1" else "4")))
+    NMAIN_DEFAULT = "2" if world == 1 else "1"  # (N > 1: one main stream -- collectives in strict step order, as rehearsed)
+    NSETS = max(1, int(os.environ.get("GHF_BENCH_SETS", "3" if os.environ.get("GHF_BENCH_MAINS", NMAIN_DEFAULT) == "1" else "4")))
 
     class BufSet:
         pass
@@ -301,10 +302,13 @@ def main():
     # GHF_BENCH_K1_STREAM=1: the histograms get a high-priority stream of their own, so that K1 of a later step fills the
     # ramp-up and the tail of K5 / K7 of the current one (all three only stream through HBM)
     pre = torch.cuda.Stream(priority=-1) if os.environ.get("GHF_BENCH_K1_STREAM", "0") == "1" else main
-    # GHF_BENCH_MAINS=2 (experiment): even and odd steps pack and decode on two high-priority streams, so that one step's K5
-    # fills the tail of the other's K7.  Needs an even number of buffer sets and of steps in flight (a set / a context slot
-    # is then always used from the same stream).  Per-kernel durations are measured under that overlap.
-    NMAIN = int(os.environ.get("GHF_BENCH_MAINS", "1"))
+    # GHF_BENCH_MAINS=2 (the default at N = 1): even and odd steps pack and decode on two high-priority streams, so that one
+    # step's K5 fills the ramp and the tail of the other's K7 (+6 % throughput at 256 MiB, profiles/r03/experiments/
+    # bench_b_m2_k0.json).  Needs an even number of buffer sets and of steps in flight (a set / a context slot is then always
+    # used from the same stream).  The events of the timed region then time kernels that SHARE the GPU (`stage_ms`); the
+    # kernels' own durations -- what `roofline` prices -- come from a separate pass over the same buffers with nothing
+    # else running (`stage_ms_alone`, measured right behind the timed region).
+    NMAIN = int(os.environ.get("GHF_BENCH_MAINS", NMAIN_DEFAULT))
     mains = [main] + [torch.cuda.Stream(priority=-1) for _ in range(NMAIN - 1)]
     # Steps in flight.  Steady state needs three; more let the main stream count the first inputs while the FIRST step's
     # one-wave code build (nothing to overlap it with at the start of a run) is still going.
@@ -515,22 +519,56 @@ def main():
     comp_bytes = int(sets[(max(args.warmup, 1) - 1) % NSETS].end[1].item())
 
     elapsed = job.measure(args.steps, world > 1)
+    verify_sets("timed region")  # what the timed steps left in the buffers decodes back to the inputs
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage_ms = job.stage_ms()
+
+    def alone_ms(reps=20):
+        """every streaming kernel's OWN duration: one kernel at a time on the main stream, nothing else queued anywhere, HIP
+        events on that stream around each launch, rotating over the buffer sets (the same bytes the timed region moved)"""
+        torch.cuda.synchronize()
+        acc = {"histogram": [], "build_code": [], "plan": [], "emit": [], "decode": []}
+        cx = ctxs[0]
+        cx.use_stream(main)
+        flags = local_flags  # (N > 1: the shard as a whole stream -- the kernels' own time does not depend on the collectives)
+        for r in range(reps):
+            b = sets[r % NSETS]
+            b.index.flags = 0
+
+            def ev(name, fn):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                fn()
+                e1.record(main)
+                acc[name].append((e0, e1))
+
+            ev("histogram", lambda: cx.histogram(b.d_in, out=hists[0]))
+            ev("build_code", lambda: cx.build_code(hists[0], codes[0]))
+            ev("plan", lambda: cx.encode_plan(b.d_in, codes[0], total=t_total[0]))
+            ev("emit", lambda: cx.encode_emit(b.d_in, codes[0], b.out, flags=flags, index=b.index, end=b.end))
+            cx.decode_prepare(codes[0])  # (k_build_decode_tables: a side-stream kernel of the pipeline, not part of K7)
+            ev("decode", lambda: cx.decode(b.out, bound, codes[0], b.index, d_out=b.dec, nbytes=t_nbytes))
+            torch.cuda.synchronize()  # one launch in flight at a time, and no host queueing effects in the events
+        cx.sync()
+        return {k: sum(a.elapsed_time(z) for a, z in v) / len(v) for k, v in acc.items()}
+
+    wd.enter("per-kernel pass")
+    stage_alone = alone_ms()
+    verify_sets("per-kernel pass")
     wd.enter("done")
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         total_in = n * world
         value = total_in * args.steps / elapsed / 1e9
-        enc_ms = sum(stage_ms[k] for k in names[:7])  # un-overlapped sum of the encode stages
+        enc_ms = sum(stage_alone.get(k, 0.0) for k in names[:7])  # un-overlapped sum of the encode stages
         # roofline of the dominant kernel (algorithmic bytes, SURVEY 8d): emit reads N and writes the body,
         # decode reads C and writes N, histogram reads N
-        cand = {"k_emit": (n + comp_bytes, stage_ms["emit"]), "k_decode": (comp_bytes + n, stage_ms["decode"]),
-                "k_histogram": (n, stage_ms["histogram"])}
+        cand = {"k_emit": (n + comp_bytes, stage_alone["emit"]), "k_decode": (comp_bytes + n, stage_alone["decode"]),
+                "k_histogram": (n, stage_alone["histogram"])}
         dom = max(cand, key=lambda k: cand[k][1])
         ach = cand[dom][0] / (cand[dom][1] * 1e-3) / 1e9
         traffic = None
@@ -552,12 +590,16 @@ def main():
                        "collectives": "none" if world == 1 else "all_reduce(256 x i64) + all_gather(1 x i64) per step",
                        "world_size": world, "collective_path": coll_path, "backend": ("none" if world == 1 else ("rccl (torch.distributed nccl)" if args.backend == "nccl" else "gloo (rehearsal)")),
                        "buffer_sets": NSETS, "side_streams": NSIDE, "histogram_stream": "own" if pre is not main else "main", "communicators": len(comms) if comms else 0,
-                       "pipeline": "steps software-pipelined, up to %d in flight (one ghf context each, %d side stream(s)), rotating over %d sets of {input, output, decoded, side-car} buffers: main stream = histogram of step i+%d, emit + decode of step i; side stream(s), ahead of the main one = histogram all-reduce, one-wave code build, chunk pricing, decode tables, offset all-gather" % (DEPTH, NSIDE, NSETS, DEPTH - 1)},
-            "encode_GBps": round(n * world / (enc_ms * 1e-3) / 1e9, 3), "decode_GBps": round(n * world / (stage_ms["decode"] * 1e-3) / 1e9, 3),
+                       "pipeline": "steps software-pipelined, up to %d in flight (one ghf context each, %d side stream(s)), rotating over %d sets of {input, output, decoded, side-car} buffers: main stream = histogram of step i+%d, emit + decode of step i%s; side stream(s), ahead of the main one = histogram all-reduce, one-wave code build, chunk pricing, decode tables, offset all-gather.  stage_ms = events inside the timed region (kernels of different streams share the GPU); stage_ms_alone and roofline = a separate pass behind it, one kernel at a time" % (DEPTH, NSIDE, NSETS, DEPTH - 1, " (even and odd steps on two main streams)" if NMAIN > 1 else "")},
+            "main_streams": NMAIN,
+            "encode_GBps": round(n * world / (enc_ms * 1e-3) / 1e9, 3), "decode_GBps": round(n * world / (stage_alone["decode"] * 1e-3) / 1e9, 3),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "stage_ms_alone": {k: round(v, 4) for k, v in stage_alone.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, builder-run, corrected as the guide prescribes; not measured in this run)" if traffic is not None else None,
                          "algorithmic_bytes_per_launch": cand[dom][0], "avg_launch_ms": round(cand[dom][1], 4),
+                         "timed_by": "HIP events on the kernel's stream around each of 20 launches, one kernel on the GPU at a time, right behind the timed region (stage_ms_alone); the same kernel inside the timed region, sharing the GPU with the other stream's kernels: %.4f ms (stage_ms)" % stage_ms[{"k_emit": "emit", "k_decode": "decode", "k_histogram": "histogram"}[dom]],
                          "all_kernels": {k: {"achieved": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
                                          for k, v in cand.items() if v[1] > 0}},
             "library": ghf.lib_identity(),
@@ -606,7 +648,7 @@ def main():
             cx.sync()
             ok_f = int(t_nbytes.item()) == n and (args.no_verify or bool((b.dec[:n] == b.d_in).all().item()))
             res["decode_foreign"] = {"GBps": round(n / tf / 1e9, 3), "ms": round(tf * 1e3, 4), "round_trip_ok": bool(ok_f),
-                                     "vs_indexed_decode": round(tf * 1e3 / stage_ms["decode"], 2) if stage_ms["decode"] else None,
+                                     "vs_indexed_decode": round(tf * 1e3 / stage_alone["decode"], 2) if stage_alone["decode"] else None,
                                      "what": "ghf_decode(index = NULL): K6 side-car reconstruction + K7, host wall time per stream"}
         if world > 1 and args.backend == "nccl":
             try:

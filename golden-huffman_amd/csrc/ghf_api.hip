@@ -782,16 +782,6 @@ int ghf_decoded_size(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, c
   return GHF_OK;
 }
 
-// TUNING (round 4, to be fixed by measurement): share of K7's rounds that waves own by stride before tickets take over
-static uint32_t k7_static_permille() {
-  static const uint32_t v = [] {
-    const char* e = std::getenv("GHF_K7_STATIC");
-    long x = e ? std::strtol(e, nullptr, 10) : 0;
-    return (uint32_t)(x < 0 ? 0 : x > 1000 ? 1000 : x);
-  }();
-  return v;
-}
-
 int ghf_decode_prepare(ghf_ctx* c, const ghf_code* d_code) {
   if (!c || !d_code) return GHF_E_INVAL;
   GHF_HIP(c, hipSetDevice(c->device));
@@ -841,7 +831,6 @@ int ghf_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, const g
   p.n_symbols = index->n_symbols;
   p.n_segs = index->n_segs;
   p.no_end_mark = (index->flags & GHF_INDEX_NO_END_MARK) ? 1u : 0u;
-  p.static_permille = k7_static_permille();
   p.out = d_out;
   p.status = c->d_status;
   p.out_bytes = d_out_bytes;
@@ -1064,7 +1053,6 @@ int ghf_crs_decode(ghf_ctx* c, const uint8_t* d_stream, size_t stream_bytes, int
   p.seg_bit = index->d_seg_bit;
   p.n_symbols = index->n_symbols;
   p.n_segs = index->n_segs;
-  p.static_permille = k7_static_permille();
   p.no_end_mark = 1u;  // there is none in this format; the end of every segment but the last is checked against the side-car
   p.out = d_out;
   p.status = c->d_status;

@@ -225,7 +225,13 @@ constexpr int kDec7InWords = kDec7InBytes / 4;
 constexpr int kDec7TileLog = kDec7InBytes + 128;                  // logical bytes per wave (16 zero bytes + slack behind the span)
 constexpr int kDec7TilePhys = kDec7TileLog / 128 * 144;           // 5328
 static_assert(kDec7TileLog % 128 == 0 && kDec7TilePhys >= 4096 + 16, "tile doubles as the 4 KiB transposition buffer");
-__device__ __forceinline__ uint32_t in_phys(uint32_t la) { return la + ((la >> 7) << 4); }
+__device__ __forceinline__ uint32_t in_phys(uint32_t la) {
+  // two instructions, v_lshrrev + v_lshl_add (left to itself the compiler canonicalises (la >> 7) << 4 into shift, mask, add:
+  // three -- and this sits in every window refill of every decoder)
+  uint32_t t = la >> 7;
+  asm("" : "+v"(t));
+  return (t << 4) + la;
+}
 struct DecLds7 {
   alignas(128) uint8_t in[kDec7Waves * kDec7TilePhys];  // compressed spans of the waves' groups, big-endian words, padded; then their output
   alignas(16) uint32_t lut[kDec7LutSlots + kDec7SmallSlots];
@@ -360,22 +366,32 @@ __device__ __forceinline__ uint32_t dec_long_entry_at(const LT& L, uint64_t W, u
   la += 12u
 #define GHF_WINDOW_USED() ((la - la0 - 12u) * 8u + o - pos)  // (la - la_first - 12) * 8 + o - o0, la_first and o0 being pos's two halves
 
-// HOT: the 64 symbols of a full, staged segment.  Straight-line code; the 64 bytes stay in registers.  LONG: codes beyond the
-// direct table exist (max_len > 12: Zipf 1.1 over 256 values has 13..14-bit codes for its rarest ones and the end mark at
-// 256 MiB) and take the reference's linear extension on a miss.  Returns the OR of all entries (kEntEnd / kEntNone set: not
-// 64 data symbols -> corrupt).  Every variant ends in the same four stores (the callers' copy-out), so that the compiler can
-// count the kernel's memory operations whichever variant runs.
+// HOT: the 64 symbols of a full, staged segment; the 64 bytes stay in registers.  LONG: codes beyond the direct table exist
+// (max_len > 12: Zipf 1.1 over 256 values has 13..14-bit codes for its rarest ones and the end mark at 256 MiB) and take the
+// reference's linear extension on a miss.  Returns the OR of all entries (kEntEnd / kEntNone set: not 64 data symbols ->
+// corrupt).  Every variant ends in the same four stores (the callers' copy-out), so that the compiler can count the kernel's
+// memory operations whichever variant runs.
+//
+// A LOOP, not 64 unrolled lookups: round 3's (and this round's first) straight-line form made a pass 8..9 KB of code, and
+// instruction fetch is what bounds such code on this part -- a loop body beyond ~4 KB issues at HALF the rate of a short
+// one (scratch/ifetch.hip, profiles/r04/ifetch.txt: 2.7 -> 5.4 cycles per 8-byte VALU instruction and SIMD with four waves
+// on it; one wave alone 5 -> 10): with 10..12 VALU instructions per symbol that, not the LDS round trip in a lane's chain
+// and not the VALU rate, set K7's time ("instruction count is not time" of round 3 was this).  The body is one period of
+// the refill pattern -- lcm(4, K) symbols, at most 12 = about 0.8 KB -- and the decoded dwords go to out[] through the
+// uniform loop counter (s_set_gpr_idx: no scratch).
+typedef uint32_t DecOut __attribute__((ext_vector_type(16)));  // a lane's 64 decoded bytes: a register TUPLE, so that out[t] with a
+                                                                // uniform t is an indexed register move and never memory
 template <int K, bool LONG, typename LT>
 __device__ __forceinline__ uint32_t dec_hot(const LT& L, const uint8_t* lin, uint32_t la0, const DecLut& T, int lut_bits, int max_len, uint32_t pos,
-                                            uint32_t (&out)[16], uint32_t& used) {
+                                            DecOut& out, uint32_t& used) {
   GHF_WINDOW_OPEN();
   uint32_t acc = 0;
-#pragma unroll
-  for (int d = 0; d < 16; ++d) {
+  constexpr int PER = (K == 3) ? 3 : 1;  // dwords per trip: the refill checks of a trip sit at the same symbols in every trip
+  auto dword = [&](int sym0) -> uint32_t {  // symbols sym0 .. sym0 + 3 of the trip -> one output dword
     uint32_t e[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if ((4 * d + j) % K == 0) GHF_REFILL();
+      if ((sym0 + j) % K == 0) GHF_REFILL();
       const uint32_t v = (uint32_t)((W << o) >> 32);
       uint32_t ent = dec_lookup(T, v);
       if (LONG && __builtin_expect((ent & kEntNone) != 0, 0)) ent = dec_long_entry(L, v, lut_bits, max_len);
@@ -386,84 +402,44 @@ __device__ __forceinline__ uint32_t dec_hot(const LT& L, const uint8_t* lin, uin
     // byte 0 of four entries -> one dword (v_perm_b32): {a.b0, b.b0} then {lo16, hi16}
     const uint32_t lo = __builtin_amdgcn_perm(e[1], e[0], 0x0C0C0400u);
     const uint32_t hi = __builtin_amdgcn_perm(e[3], e[2], 0x0C0C0400u);
-    out[d] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-    // pack HERE: left alone, the scheduler sinks these five instructions behind the last lookup and keeps all 64 raw entries
-    // alive until then -- 64 registers instead of 16, which is what pushed round 3's kernel over its 128 and into scratch
-    __builtin_amdgcn_sched_barrier(0);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+  };
+#pragma unroll 1
+  for (int t = 0; t < 16 / PER; ++t) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) out[t * PER + i] = dword(4 * i);
   }
+#pragma unroll
+  for (int d = 16 / PER * PER; d < 16; ++d) out[d] = dword(4 * d);  // (K = 3: the sixteenth dword; 60 is a multiple of 3)
   used = GHF_WINDOW_USED();
   return acc;
 }
 
 // HOT, small alphabet (2 * max_len <= 10): any two codes fit lut2's index, so one lookup yields two symbols and the serial
-// shift -> lookup -> add chain is half as long.  Three lookups (<= 30 bits) per refill check.
+// shift -> lookup -> add chain is half as long.  Three lookups (<= 30 bits) per refill check: a trip is six lookups, three dwords.
 // entry = sym0 | sym1 << 8 | (len0 + len1) << 16 | bit 30: not two data symbols
-__device__ __forceinline__ uint32_t dec_hot_pair(const uint8_t* lin, uint32_t la0, const DecLut& T2, uint32_t pos, uint32_t (&out)[16], uint32_t& used) {
+__device__ __forceinline__ uint32_t dec_hot_pair(const uint8_t* lin, uint32_t la0, const DecLut& T2, uint32_t pos, DecOut& out, uint32_t& used) {
   GHF_WINDOW_OPEN();
   uint32_t acc = 0;
-#pragma unroll
-  for (int d = 0; d < 16; ++d) {
+  auto dword = [&](int look0) -> uint32_t {  // lookups look0, look0 + 1 of the trip -> four symbols
     uint32_t e[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      if ((2 * d + j) % 3 == 0) GHF_REFILL();
+      if ((look0 + j) % 3 == 0) GHF_REFILL();
       const uint32_t ent = dec_lookup(T2, (uint32_t)((W << o) >> 32));
       o += (ent >> 16) & 0xFFu;
       e[j] = ent;
     }
     acc |= e[0] | e[1];
-    out[d] = __builtin_amdgcn_perm(e[1], e[0], 0x05040100u);  // {a.sym0, a.sym1, b.sym0, b.sym1}
-    __builtin_amdgcn_sched_barrier(0);  // (as in dec_hot: pack now, do not keep the raw entries)
+    return __builtin_amdgcn_perm(e[1], e[0], 0x05040100u);  // {a.sym0, a.sym1, b.sym0, b.sym1}
+  };
+#pragma unroll 1
+  for (int t = 0; t < 5; ++t) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[t * 3 + i] = dword(2 * i);
   }
+  out[15] = dword(30);
   used = GHF_WINDOW_USED();
-  return acc;
-}
-
-// HOT, codes of (at most) TWO lengths L and L + 1 -- bytes that do not compress: 255 codes of 8 bits, two of 9.  Which of the
-// two a code has is one comparison of the next bits with the first L-bit code (canonical codes: the longer ones are the
-// numerically smaller ones, canonical_huff_encoder.cc:446-450), so the serial chain of a lane is shift -> compare -> add-with-
-// carry on REGISTERS -- 3 instructions, ~35 cycles with four waves on the SIMD -- and the table lookups hang off it instead of
-// being its links (with the lookup in the chain a symbol took 138 cycles, 57 of them the LDS round trip alone:
-// profiles/r04/k7_timeline_*.json, valu_lat.txt).  The refill is branch-free (a lane that needs no new word re-reads the one it
-// has), so the 64 symbols are ONE basic block; entries are packed one dword behind the lookups that fetch them.
-template <int K>
-__device__ __forceinline__ uint32_t dec_hot_two(const uint8_t* lin, uint32_t la0, const DecLut& T, uint32_t thr, uint32_t lmin, uint32_t pos,
-                                                uint32_t (&out)[16], uint32_t& used) {
-  uint32_t la = la0 + ((pos >> 5) << 2);
-  uint32_t o = pos & 31u;
-  uint32_t hi = in_word(lin, la), lo = in_word(lin, la + 4u), nx = in_word(lin, la + 8u);
-  la += 8u;  // nx is the word at la
-  uint32_t acc = 0;
-  uint32_t e[4] = {0, 0, 0, 0}, p[4];
-#pragma unroll
-  for (int d = 0; d <= 16; ++d) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = e[j];
-    if (d < 16) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if ((4 * d + j) % K == 0) {  // o <= 31 behind this, o + K * (L + 1) <= 63 before the next one
-          const bool mv = o >= 32u;
-          hi = mv ? lo : hi;
-          lo = mv ? nx : lo;
-          la += mv ? 4u : 0u;
-          o &= 31u;
-          nx = in_word(lin, la);  // (needed one refill from now)
-        }
-        const uint32_t v = (uint32_t)(((((uint64_t)hi << 32) | lo) << o) >> 32);
-        e[j] = dec_lookup(T, v);
-        o += lmin + (v < thr ? 1u : 0u);
-      }
-    }
-    if (d > 0) {
-      acc |= p[0] | p[1] | p[2] | p[3];
-      const uint32_t l2 = __builtin_amdgcn_perm(p[1], p[0], 0x0C0C0400u);
-      const uint32_t h2 = __builtin_amdgcn_perm(p[3], p[2], 0x0C0C0400u);
-      out[d - 1] = __builtin_amdgcn_perm(h2, l2, 0x05040100u);
-    }
-    __builtin_amdgcn_sched_barrier(0);  // (as in dec_hot: pack now, do not collect raw entries)
-  }
-  used = (la - la0 - 8u) * 8u + o - pos;
   return acc;
 }
 
@@ -521,7 +497,7 @@ __device__ __forceinline__ uint32_t dec_cold(const DecLds7& L, const DecIn<STAGE
 // The loop is software-pipelined over groups so that no HBM latency is exposed and nothing but the copy into LDS stands
 // between the arrival of a span and the request for the next one: while group i is decoded, the span of group i+1 is in
 // flight into registers, the descriptor of group i+1 (where to load, where every lane starts) was computed a pass earlier,
-// the side-car words of group i+2 are in flight, the number of group i+3 is known and the ticket for group i+4 is in flight.
+// the side-car words of group i+2 are in flight and the ticket for group i+3 is in flight.
 //
 // Round 3's form of this loop computed the next group's descriptor between the copy into LDS and the loads, held six
 // instantiations of the whole loop nest (one per decoder variant, each with its own cold path) and was spilled by the
@@ -607,7 +583,6 @@ __device__ __forceinline__ void latch_status_here(int* st, int code) {
 }
 
 constexpr int kDecVec = (kDec7InBytes + 1023) / 1024;  // 16-byte vectors per lane that cover a staged span
-constexpr int kDecStatic = 4;                           // groups every wave owns without asking (its pipeline depth)
 
 __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
   __shared__ DecLds7 L;
@@ -624,37 +599,35 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
   C.ngroups = (uint32_t)((P.n_segs + 63) >> 6);
   const uint32_t ngroups = C.ngroups, glast = ngroups - 1;
   auto clampg = [&](uint32_t g) { return g < ngroups ? g : glast; };  // past the end: redundant, harmless loads
-  // Groups.  Every wave owns its first kDecStatic groups and, by stride, its share of the first `nstat` rounds; the rest is
-  // handed out by ticket counters, so that a workgroup that starts late (another kernel occupied its CU) or runs slowly
-  // takes fewer groups instead of becoming the launch's straggler.  16 classes of workgroups, one counter each on its own
-  // 128-byte line (one word saturates at ~88 tickets per microsecond); class c owns the ticketed groups == c (mod 16).
+  // Groups.  A wave owns ONE group by its number (wid); every other one comes from a ticket counter, so that a workgroup that
+  // starts late (a 16-wave workgroup needs a whole CU: one wave of another kernel on it -- K2 of a later step in the
+  // pipelined bench -- and it waits for that kernel or for another K7 workgroup to end) owns 16 groups, not more: round 3 gave
+  // every wave three groups and the first form of this loop four, and in the pipelined bench that workgroup's 64 groups ran
+  // alone behind everybody else's last one (decode 0.135 ms alone, 0.159 in the pipeline).  16 classes of workgroups, one
+  // counter each on its own 128-byte line (one word saturates at ~88 tickets per microsecond); class c owns the ticketed
+  // groups == c (mod 16).  The first ticket is worth two groups (the depth of the pipeline) and is drawn before the
+  // tables are copied in, which hides its round trip.
   const uint32_t nwaves = gridDim.x * kDec7Waves;
   const uint32_t wid = blockIdx.x * kDec7Waves + (uint32_t)wave;
   const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;  // every class needs at least one workgroup
   const uint32_t cls = blockIdx.x % ncls;
-  uint32_t nstat = (uint32_t)((uint64_t)(ngroups / nwaves) * P.static_permille / 1000u);
-  if (nstat < (uint32_t)kDecStatic) nstat = kDecStatic;
-  uint32_t claims = kDecStatic;  // groups this wave has asked for so far
   uint32_t* const my_ticket = &P.dt->ticket[cls * 32];
-  auto claim_issue = [&]() -> unsigned int {  // the atomic's return value stays in a VGPR until claim_group() needs it, a pass later
+  auto claim_issue = [&](unsigned int count) -> unsigned int {  // the atomic's return value stays in a VGPR until claim_group() needs it, a pass later
     unsigned int t = 0;
-    if (claims >= nstat && lane == 0) t = atomicAdd(my_ticket, 1u);
-    ++claims;
+    if (lane == 0) t = atomicAdd(my_ticket, count);
     return t;
   };
-  auto claim_group = [&](unsigned int t) -> uint32_t {  // the group of the claim issued last (saturating: past the end stays past the end)
-    const uint32_t c = claims - 1;
-    const uint64_t g = c < nstat ? (uint64_t)wid + (uint64_t)c * nwaves
-                                 : (uint64_t)nstat * nwaves + (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * ncls + cls;
+  auto claim_group = [&](unsigned int t, uint32_t k) -> uint32_t {  // group of ticket t + k (saturating: past the end stays past the end)
+    const uint64_t g = (uint64_t)nwaves + ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) + k) * ncls + cls;
     return g < 0xFFFFFFFFull ? (uint32_t)g : 0xFFFFFFFFu;
   };
-  uint32_t g0 = wid, g1 = wid + nwaves, g2 = wid + 2 * nwaves, g3 = wid + 3 * nwaves;
+  uint32_t g0 = wid, g1, g2;
+  const unsigned int tk0 = claim_issue(2);
 
   // The first two groups' side-car words are requested BEFORE the tables are pulled in: one of the dependent memory round
   // trips in front of the first decode hides behind the table copy.
   DecMeta M0, M;
   dec_issue_meta(P, C, clampg(g0), lane, M0);
-  dec_issue_meta(P, C, clampg(g1), lane, M);
   if (tid == 0) L.status0 = *P.status;  // one read per workgroup: whether the launch does anything must be uniform
   const int lut_bits = P.dt->lut_bits, max_len = P.dt->max_len;
   const int pair_bits = P.dt->pair_bits;
@@ -689,13 +662,7 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
     // refill brings it back below 32.  With 33 -- max_len 11, K = 3 -- o could reach 64, stay at 32 behind the refill, and
     // the third lookup of the next round would read past the window: six 11-bit codes in a row at the right phase, found by
     // scratch/host_soak.py)
-    // 6..8: canonical codes of at most two lengths that the table resolves (max_len 6..8 / 9, 10 / 11, 12): the length chain runs
-    // on registers (dec_hot_two), K = 4 / 3 / 2
-    const int min_len = P.dt->min_len;
-    const bool two = P.dt->kind == 0 && !pair_bits && max_len - min_len <= 1 && max_len <= kDecLutBitsMax && max_len >= 6;
-    const uint32_t two_thr = max_len > min_len ? P.dt->fc_left[min_len & 31] : 0u;
-    const int var = two ? (max_len <= 8 ? 6 : max_len <= 10 ? 7 : 8)
-                        : pair_bits ? 0 : max_len <= 8 ? 1 : max_len <= 10 ? 2 : max_len <= kDecLutBitsMax ? 3 : max_len <= 16 ? 4 : 5;
+    const int var = pair_bits ? 0 : max_len <= 8 ? 1 : max_len <= 10 ? 2 : max_len <= kDecLutBitsMax ? 3 : max_len <= 16 ? 4 : 5;
     const uint8_t* const lin = L.in;
     const uint32_t la0 = (uint32_t)wave * kDec7TileLog;             // this wave's tile in the logical (unpadded) byte space
     uint32_t* const tile = reinterpret_cast<uint32_t*>(L.in + (uint32_t)wave * kDec7TilePhys);  // ... and as plain memory (copy-out)
@@ -713,9 +680,12 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
     uint4 R[kDecVec];
     dec_group(P, C, clampg(g0), lane, M0, cur);
     issue(cur, R, lane);
-    dec_group(P, C, clampg(g1), lane, M, nxt);
+    g1 = claim_group(tk0, 0);
+    g2 = claim_group(tk0, 1);
+    dec_issue_meta(P, C, clampg(g1), lane, M);
+    unsigned int tk = claim_issue(1);  // for the group after g2
+    dec_group(P, C, clampg(g1), lane, M, nxt);  // (the one dependent side-car round trip of a wave's life; the first span is in flight meanwhile)
     dec_issue_meta(P, C, clampg(g2), lane, M);
-    unsigned int tk = claim_issue();  // for the group after g3
 
     // One pass over a group.  HOT = the group is complete, staged, plausible and not the stream's last: the body then has
     // no data-dependent branch around its memory operations, so the compiler can count them -- the wait for the
@@ -758,16 +728,13 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
       const uint64_t sym0 = seg * kSegSymbols;
       if (HOT) {
         uint32_t used, acc;
-        uint32_t out[16];
+        DecOut out;
         if (var == 0) acc = dec_hot_pair(lin, la0, lut2(ln), cur.pos, out, used) >> 14;  // bit 30 -> bit 16
         else if (var == 1) acc = dec_hot<4, false>(L, lin, la0, lut1(ln), lut_bits, max_len, cur.pos, out, used);
         else if (var == 2) acc = dec_hot<3, false>(L, lin, la0, lut1(ln), lut_bits, max_len, cur.pos, out, used);
         else if (var == 3) acc = dec_hot<2, false>(L, lin, la0, lut1(ln), lut_bits, max_len, cur.pos, out, used);
         else if (var == 4) acc = dec_hot<2, true>(L, lin, la0, lut1(ln), lut_bits, max_len, cur.pos, out, used);
-        else if (var == 5) acc = dec_hot<1, true>(L, lin, la0, lut1(ln), lut_bits, max_len, cur.pos, out, used);
-        else if (var == 6) acc = dec_hot_two<4>(lin, la0, lut1(ln), two_thr, (uint32_t)min_len, cur.pos, out, used);
-        else if (var == 7) acc = dec_hot_two<3>(lin, la0, lut1(ln), two_thr, (uint32_t)min_len, cur.pos, out, used);
-        else acc = dec_hot_two<2>(lin, la0, lut1(ln), two_thr, (uint32_t)min_len, cur.pos, out, used);
+        else acc = dec_hot<1, true>(L, lin, la0, lut1(ln), lut_bits, max_len, cur.pos, out, used);
         // copy-out through the input tile (dead now): lane-major 64-byte rows, pieces XOR-swizzled so that the 16
         // lanes of a write phase hit 16 different bank groups; then four fully coalesced 1 KiB stores per wave,
         // straight-line, so that the compiler can count them
@@ -812,10 +779,10 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
       dec_group(P, C, clampg(g2), ln, M, nxt);
       g0 = g1;
       g1 = g2;
-      g2 = g3;
-      g3 = claim_group(tk);
+      g2 = claim_group(tk, 0);  // (drawn a pass ago: a wave holds two groups beyond the one it decodes -- what it still has to do
+                                //  when the counters run dry is the launch's tail)
       dec_issue_meta(P, C, clampg(g2), ln, M);
-      tk = claim_issue();
+      tk = claim_issue(1);
     };
     while (g0 < ngroups) {
       if (cur.hot) {

@@ -109,7 +109,6 @@ struct DecParams {
   uint64_t n_symbols;
   uint64_t n_segs;
   uint32_t no_end_mark;  // the last symbol is not followed by the end mark (a shard that is not the stream's last)
-  uint32_t static_permille;  // share of a wave's rounds it owns by stride before the ticket counters take over (0..1000)
   uint8_t* out;
   uint64_t* out_bytes;  // optional device u64 <- n_symbols
   int* status;

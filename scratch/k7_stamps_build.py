@@ -34,7 +34,7 @@ rep("        // copy-out through the input tile (dead now)",
 rep("        if (used != cur.expect) acc |= kEntNone;\n        bad_acc |= acc;",
     "        if (used != cur.expect) acc |= kEntNone;\n        bad_acc |= acc;\n        const uint64_t st3 = __builtin_amdgcn_s_memtime();\n"
     "        st_a += st1 - st0; st_b += st2 - st1; st_c += st3 - st2; st_n += 1; st_d -= st3;")
-rep("      tk = claim_issue();\n    };", "      tk = claim_issue();\n      if (HOT) st_d += __builtin_amdgcn_s_memtime();\n    };")
+rep("      tk = claim_issue(1);\n    };", "      tk = claim_issue(1);\n      if (HOT) st_d += __builtin_amdgcn_s_memtime();\n    };")
 rep("    if (bad_acc & (kEntEnd | kEntNone)) latch_status_here",
     "    if (lane == 0) { uint64_t* dbg = reinterpret_cast<uint64_t*>(P.out + ((P.n_symbols + 255) & ~255ull)) + (uint64_t)wid * 8;"
     " dbg[0] = st_a; dbg[1] = st_b; dbg[2] = st_c; dbg[3] = st_d; dbg[4] = st_n; dbg[5] = __builtin_amdgcn_s_memtime() - st_begin;"

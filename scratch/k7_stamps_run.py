@@ -39,9 +39,15 @@ t0 = begin.min()
 print(json.dumps({
     "mib": mib, "kind": kind, "decode_event_ms": round(e0.elapsed_time(e1), 4),
     "passes_per_wave": [float(np_.min()), float(np_.mean()), float(np_.max())],
-    "per_pass_cycles": {"wait+stage+issue": round(float((a / np_).mean()), 1), "decode": round(float((b / np_).mean()), 1),
-                        "copy_out": round(float((c_ / np_).mean()), 1), "descr+meta+ticket": round(float((d / np_).mean()), 1)},
+    "per_pass_cycles": {"wait+stage+issue": round(float(a.sum() / np_.sum()), 1), "decode": round(float(b.sum() / np_.sum()), 1),
+                        "copy_out": round(float(c_.sum() / np_.sum()), 1), "descr+meta+ticket": round(float(d.sum() / np_.sum()), 1)},
+    "pass_cycles_by_wave_quartile": [round(float(x), 0) for x in np.percentile((a + b + c_ + d) / np_, [5, 25, 50, 75, 95])],
     "wave_life_cycles": [float(life.min()), float(life.mean()), float(life.max())],
     "first_start_to_last_end_cycles": float(endt.max() - t0), "start_spread_cycles": float(begin.max() - t0),
     "end_spread_cycles": float(endt.max() - endt.min()),
-    "sum_stamped_over_life": round(float(((a + b + c_ + d) / life).mean()), 3)}))
+    "sum_stamped_over_life": round(float(((a + b + c_ + d) / life).mean()), 3),
+    "passes_by_wave_of_workgroup": [round(float(x), 1) for x in np_.reshape(256, 16).mean(axis=0)],
+    "passes_per_workgroup_min_mean_max": [float(np_.reshape(256, 16).sum(axis=1).min()), float(np_.reshape(256, 16).sum(axis=1).mean()), float(np_.reshape(256, 16).sum(axis=1).max())],
+    "passes_by_xcd": [round(float(x), 1) for x in np_.reshape(32, 8, 16).sum(axis=2).mean(axis=0)],
+    "decode_cycles_per_pass_by_wave_of_workgroup": [round(float(x), 0) for x in (b.reshape(256, 16).sum(axis=0) / np_.reshape(256, 16).sum(axis=0))],
+    "wait_cycles_per_pass_by_wave_of_workgroup": [round(float(x), 0) for x in (a.reshape(256, 16).sum(axis=0) / np_.reshape(256, 16).sum(axis=0))]}))

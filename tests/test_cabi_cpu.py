@@ -214,19 +214,30 @@ def test_k6_kernels_use_no_scratch():
         assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) == 0, sym
 
 
-def test_decode_kernel_scratch_reloads_are_followed_by_full_waits():
+def test_decode_kernel_uses_no_scratch_and_counts_its_waits():
+    """K7 (k_decode).  Round 3's build spilled the fifth vector of its prefetch INSIDE the hot loop of the variants uniform
+    bytes take: `global_load ... ; s_waitcnt vmcnt(0) ; scratch_store` -- every pass waited for the whole prefetch before it
+    decoded a symbol (profiles/r04/k7_spill_r03.txt).  Now: no scratch at all, a register budget with room (a 16-wave
+    workgroup at <= 96 registers shares its CU with the one-wave code build of a later step instead of waiting for it), and
+    the hot pass's wait for the span prefetched a pass ago is a COUNTED one (all but the youngest six or more vector-memory
+    operations: this pass's stores, the next side-car words, the ticket), never a full drain."""
     text = _kernel_asm("ghf_decode")
-    # K7 may spill (its 128-VGPR budget is tight), but only where it does no harm: every scratch reload must be
-    # followed by a FULL vector-memory wait before any counted one (so nothing is ever inferred from the order in
-    # which a scratch reload and a global load retire)
-    body = text[text.index("_ZN3ghf8k_decodeENS_9DecParamsE:") :]
+    sym = "_ZN3ghf8k_decodeENS_9DecParamsE"
+    meta = re.search(r"\.name:\s+%s\b(.*?)\.wavefront_size" % re.escape(sym), text, flags=re.S).group(1)
+    assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1)) == 0
+    assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) == 0
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= 96
+    body = text[text.index(sym + ":") :]
     body = body[: body.index(".Lfunc_end")].split("\n")
-    for i, line in enumerate(body):
-        if "scratch_load" in line:
-            for nxt in body[i + 1 : i + 400]:
-                w = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", nxt)
-                if w:
-                    assert w.group(1) == "0", (i, line.strip(), nxt.strip())
-                    break
-            else:
-                raise AssertionError("no vector-memory wait after the reload at line %d" % i)
+    assert not any("scratch_" in l for l in body)
+    # the hot pass: from the first non-temporal span load behind a run of counted waits back to those waits
+    nt_loads = [i for i, l in enumerate(body) if re.search(r"global_load_dwordx4 .* nt", l)]
+    assert len(nt_loads) >= 10  # prologue + hot + cold
+    counted = []
+    for i, l in enumerate(body):
+        w = re.search(r"s_waitcnt vmcnt\((\d+)\)", l)
+        if w and int(w.group(1)) >= 6:
+            counted.append((i, int(w.group(1))))
+    # five spans of a pass are waited for one by one: vmcnt(10), (9), (8), (7), (6) in this order somewhere
+    seq = [v for _, v in counted]
+    assert any(seq[k : k + 5] == [10, 9, 8, 7, 6] for k in range(len(seq))), seq
