@@ -329,6 +329,7 @@ def main():
     t_start = [torch.empty(1, dtype=torch.int64, device="cuda") for _ in range(DEPTH)]
     ev_hist = [torch.cuda.Event() for _ in range(DEPTH)]
     ev_ready = [torch.cuda.Event() for _ in range(DEPTH)]
+    ev_done = [torch.cuda.Event() for _ in range(DEPTH)]  # the slot's step has decoded: its context, code and tables may be rewritten
     t_nbytes = torch.empty(1, dtype=torch.int64, device="cuda")
     last_rank = rank == world - 1
     sharded_flags = (ghf.EMIT_LAST if last_rank else 0) | (ghf.EMIT_REBASE if rank > 0 else ghf.EMIT_HEADER)  # rank 0 writes the header
@@ -381,8 +382,11 @@ def main():
             k = i % DEPTH
             cx, h, c, side, b = ctxs[k], hists[k], codes[k], sides[i % NSIDE], sets[i % NSETS]
             comm = self.comms[i % NSIDE] if self.comms else None
-            if pre is not main and i >= DEPTH:
-                pre.wait_event(ev_ready[k])  # this slot's previous step has priced its chunks (K4 read what K1 is about to overwrite)
+            if i >= DEPTH and (pre is not main or NMAIN > 1):
+                # this slot's previous step is through: K1 overwrites the per-chunk counts its K4 read, and the side-stream
+                # kernels behind K1 rewrite the code and the decode tables its K5 / K7 read.  (With ONE main stream that carries
+                # K1 too, stream order says so already: the previous step's decode was queued on it before this K1.)
+                pre.wait_event(ev_done[k])
             cx.use_stream(pre)
             self.timed("histogram", i, record, pre, lambda: cx.histogram(b.d_in, out=h))
             ev_hist[k].record(pre)
@@ -428,6 +432,7 @@ def main():
                 b.index.flags = (0 if last_rank else ghf.INDEX_NO_END_MARK) if self.sharded else 0
                 self.timed("emit", i, rec_of(i), mstream, lambda: cx.encode_emit(b.d_in, c, b.out, start_bit=start_bit, flags=flags, index=b.index, end=b.end))
                 self.timed("decode", i, rec_of(i), mstream, lambda: cx.decode(b.out, bound, c, b.index, d_out=b.dec, nbytes=t_nbytes))
+                ev_done[k].record(mstream)
 
         def measure(self, K, barrier):
             """time exactly K steps: barrier + synchronize on both sides"""
