@@ -11,6 +11,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "ghf_internal.h"
 
@@ -158,6 +159,29 @@ int ghf_comm_allgather_total(ghf_ctx* c, ghf_comm* m, const uint64_t* d_total, u
 size_t ghf_shard_bound(size_t n) {
   size_t b = 1040 + 8 * 32 + 4 * n + 8;
   return ((b + 15) & ~(size_t)15) + 32;
+}
+
+int ghf_shard_bytes(ghf_ctx* c, const ghf_code* d_code, const uint64_t* d_totals, int world, int rank, size_t* bytes) {
+  if (!c || !d_code || !d_totals || !bytes || world < 1 || world > 4096 || rank < 0 || rank >= world) return GHF_E_INVAL;
+  if (hipSetDevice(ghf_api_device(c)) != hipSuccess) return ghf_api_fail(c, GHF_E_HIP, "hipSetDevice");
+  std::vector<uint64_t> tot((size_t)world);
+  int32_t lens[2] = {0, 0};  // min_len, max_len
+  uint32_t eof_len = 0;
+  hipStream_t s = ghf_api_stream(c);
+  hipError_t e = hipMemcpyAsync(tot.data(), d_totals, sizeof(uint64_t) * (size_t)world, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(lens, &d_code->min_len, sizeof lens, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&eof_len, &d_code->length[GHF_NSYM - 1], sizeof eof_len, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return ghf_api_fail(c, GHF_E_HIP, "ghf_shard_bytes: copy totals / code lengths to host");
+  if (lens[1] < 1 || lens[1] > 32 || eof_len > 32) return ghf_api_fail(c, GHF_E_FORMAT, "ghf_shard_bytes: bad max_len in tables");
+  // the arithmetic of K5's emit_begin (ghf_emit.hip): the shard's first bit, its last, the 16-byte units between
+  uint64_t start = 8ull * (1040ull + 8ull * (uint64_t)lens[1]);
+  for (int h = 0; h < rank; ++h) start += tot[(size_t)h];
+  uint64_t end = start + tot[(size_t)rank];
+  if (rank == world - 1) end = (end + eof_len + 7) & ~7ull;  // end mark + padding to a byte
+  const uint64_t origin = rank > 0 ? ((start >> 7) << 4) : 0ull;  // GHF_EMIT_REBASE: d_out[0] = the unit of the first bit
+  *bytes = (size_t)((((end >> 7) + 1) << 4) - origin);
+  return GHF_OK;
 }
 
 int ghf_encode_sharded(ghf_ctx* c, ghf_comm* m, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap, ghf_code* d_code,

@@ -105,7 +105,7 @@ EXPORTS = [
     "ghf_comm_unique_id", "ghf_comm_init_rank", "ghf_comm_destroy", "ghf_comm_world", "ghf_rccl_version",
     "ghf_comm_allreduce_hist", "ghf_comm_allgather_total", "ghf_encode_sharded", "ghf_shard_bound",
     "ghf_event_create", "ghf_event_destroy", "ghf_event_record", "ghf_event_wait", "ghf_event_sync", "ghf_histogram_add",
-    "ghf_crs_sync_piece", "ghf_copy_d2d",
+    "ghf_crs_sync_piece", "ghf_copy_d2d", "ghf_shard_bytes",
 ]
 COMM_ID_BYTES = 128
 
@@ -192,6 +192,7 @@ def lib():
     L.ghf_encode_sharded.argtypes = [vp, vp, vp, sz, vp, sz, vp, C.POINTER(Index), vp, vp]
     L.ghf_shard_bound.argtypes = [sz]
     L.ghf_shard_bound.restype = sz
+    L.ghf_shard_bytes.argtypes = [vp, vp, vp, i32, i32, C.POINTER(sz)]
     _lib = L
     return L
 
@@ -379,6 +380,12 @@ class Context:
             out = self.torch.empty(1, dtype=self.torch.int64, device=self.device)
         self._chk(self.L.ghf_shard_start_bit(self.h, d_code.data_ptr(), d_totals.data_ptr(), world, rank, out.data_ptr()), "ghf_shard_start_bit")
         return out
+
+    def shard_bytes(self, d_code, d_totals, world, rank):
+        """exact size of this rank's shard output, from the all-gathered bit totals (one host synchronisation)"""
+        out = C.c_size_t(0)
+        self._chk(self.L.ghf_shard_bytes(self.h, d_code.data_ptr(), d_totals.data_ptr(), world, rank, C.byref(out)), "ghf_shard_bytes")
+        return int(out.value)
 
     def index_alloc(self, n):
         idx = Index()

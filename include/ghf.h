@@ -255,7 +255,14 @@ int ghf_comm_allgather_total(ghf_ctx* ctx, ghf_comm* comm, const uint64_t* d_tot
  * (index->flags is set: GHF_INDEX_NO_END_MARK on every rank but the last). */
 int ghf_encode_sharded(ghf_ctx* ctx, ghf_comm* comm, const uint8_t* d_in, size_t n, uint8_t* d_out, size_t cap,
                        ghf_code* d_code, ghf_index* index, uint64_t* d_start_bit, uint64_t* d_end);
-size_t ghf_shard_bound(size_t n); /* header + 4 n (32 bits per symbol) + end mark + alignment slack */
+size_t ghf_shard_bound(size_t n); /* header + 4 n (32 bits per symbol) + end mark + alignment slack: what fits ANY code */
+/* The EXACT number of bytes this rank's K5 will define in d_out, from the all-gathered bit totals (ghf_comm_allgather_total)
+ * and the global code -- both known before K5 runs.  A caller that can afford ONE host synchronisation per stream (the first
+ * step of a pipeline, or a caller that is not pipelined) sizes its shard outputs with this instead of ghf_shard_bound: at
+ * BASELINE config 4 (4 GiB of uniform bytes per rank) that is 4.3 GB per buffer instead of 17.2.  Waits for the context's
+ * stream.  *bytes = what ghf_encode_emit / ghf_encode_sharded need as `cap` (whole 16-byte units, the one a shard shares with
+ * its right neighbour included); the same number K5 reports in d_end[1] afterwards, rounded up to its last unit. */
+int ghf_shard_bytes(ghf_ctx* ctx, const ghf_code* d_code, const uint64_t* d_totals, int world, int rank, size_t* bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * inputs on which the reference is undefined because a code would be longer than 32 bits

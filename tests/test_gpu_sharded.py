@@ -85,6 +85,22 @@ def _worker(rank, world, port, kind, n_total, q):
             ok = bool((back[: shard.numel()] == shard).all().item())
         except Exception:  # keep the collectives below in step with the other rank
             err = traceback.format_exc()
+        # the same shard once more into a buffer of EXACTLY ghf_shard_bytes(all-gathered totals): K5 must find it large enough
+        # (GHF_E_CAP otherwise) and write the same bytes (every rank runs this: the exchanges stay in step)
+        try:
+            exact = ctx.shard_bytes(enc["code"], enc["totals"], world, rank)
+        except Exception:
+            exact, ok, err = pkg.ghf.shard_bound(shard.numel()), False, err + traceback.format_exc()
+        small = ctx.empty_u8(exact)
+        enc2 = sharded.encode_sharded(ctx, hd, shard, out=small)
+        try:
+            ctx.sync()
+            nb = int(enc["end"][1].item())
+            assert nb <= exact <= nb + 16, (nb, exact)
+            assert int(enc2["end"][1].item()) == nb and bool((small[:nb] == enc["out"][:nb]).all().item())
+            assert exact < pkg.ghf.shard_bound(shard.numel())
+        except Exception:
+            ok, err = False, err + traceback.format_exc()
         stream = sharded.gather_stream(ctx, hd, enc)
         q.put((rank, ok, stream.tobytes() if rank == 0 else None, err))
         dist.barrier()
