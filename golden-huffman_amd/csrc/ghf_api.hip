@@ -681,7 +681,14 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
       GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 3, c->d_u64 + 3, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       GHF_HIP(c, hipStreamSynchronize(c->stream));
       if ((uint32_t)c->h_u64[5] == 0) break;
-      if (!scanned) {
+      // Not settled.  A boundary that is still moving travels ONE subsequence to the right per pass, and a pass in which
+      // little moved costs little (a wave whose 64 subsequences are current skips them), so a few more batches are cheaper
+      // than the deterministic scan over the whole stream -- which long streams of a quickly synchronising code otherwise
+      // fall into because SOME stretch among their millions of subsequences needs a fifth pass (4 GiB Zipf: 44 ms with
+      // the scan after the first batch, see profiles/r04/foreign_4GiB.txt).  Codes that do not settle in kScanAfter passes
+      // (long runs of one value, near-fixed-length codes the caller did not announce) get the scan then.
+      constexpr uint64_t kScanAfter = 16;
+      if (!scanned && passes >= kScanAfter) {
         launch_sync_scan(p, ws + o_scan, fn_stride, first_start, c->stream);
         scanned = true;
       }
