@@ -229,3 +229,70 @@ def test_crs_body_in_pieces(env, kind, n, piece):
         first = landing
     got = np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
     assert got.size == data.size and np.array_equal(got, data)
+
+
+def _comb(depth):
+    """a comb of `depth` + 1 leaves (keys 0 .. depth): leaf i hangs at depth i + 1 with the code '1' * i + '0', the last one at
+    `depth` with '1' * depth.  -> (header bytes in the reference's preorder form, codes as ints, lengths)"""
+    hdr = []
+    for i in range(depth):
+        hdr += [255, 255, 0, i]  # parent, its left child = leaf i   (huff_tree.cc:174-187: (255,255) parent / (0, key) leaf)
+    hdr += [0, depth]            # the last parent's right child
+    codes = [(1 << (i + 1)) - 2 for i in range(depth)] + [(1 << depth) - 1]
+    lens = [i + 1 for i in range(depth)] + [depth]
+    return np.array(hdr, dtype=np.uint8), codes, lens
+
+
+@pytest.mark.parametrize("depth", [33, 40, 64])
+def test_codes_of_up_to_64_bits_by_a_hand_built_tree(env, depth):
+    """k_emit_long / deposit64, the 64-bit tree walk of K7's long path, the cursors' double refill and K6's rows of stride 64
+    with codes of 40 and 64 bits.  No input makes the reference build such a tree below 2^28 (2^44) bytes, so the tree is built
+    by hand -- a comb -- and the few KiB of input use its deepest leaves back to back; expected bytes: the definition of the
+    format (every symbol's code, most significant bit first, normal_huff_encoder.h:158-186), packed on the host."""
+    ghf, ctx, torch = env
+    hdr, codes, lens = _comb(depth)
+    tree, tb = ghf.crs_parse_header(hdr)
+    assert tb == hdr.size and tree.max_len == depth and tree.n_leaves == depth + 1
+    rng = np.random.default_rng(depth)
+    # mostly the two deepest leaves (runs of them), every other leaf now and then
+    data = rng.choice(np.arange(depth + 1), size=20000 + depth, p=np.array([1.0] * (depth - 1) + [30.0, 30.0]) / (depth + 59.0)).astype(np.uint8)
+    data[1000:1300] = depth          # three hundred 64-bit (40-bit) codes in a row
+    data[5000:5064] = depth - 1
+    code = ghf.Code()
+    for s in range(ghf.NSYM):
+        code.length[s], code.codeword[s], code.symbol[s] = 0, 0, 0xFFFFFFFF
+    for s, (c, l) in enumerate(zip(codes, lens)):
+        code.length[s], code.codeword[s], code.symbol[s] = l, c & 0xFFFFFFFF, c >> 32
+    code.min_len, code.max_len = 1, depth
+    d_code = ctx.code_to_device(code)
+    d_tree = ctx.tree_to_device(tree)
+    d_in = to_dev(torch, data)
+    head = tb + 2
+    # expected body, bit by bit
+    bits = "".join(format(codes[v], "0%db" % lens[v]) for v in data.tolist())
+    nbits = len(bits)
+    body = np.frombuffer(int(bits + "0" * ((-nbits) % 8), 2).to_bytes((nbits + 7) // 8, "big"), dtype=np.uint8)
+    left = (-nbits) % 8
+    cap = ((head + body.size + 64 + 15) // 16) * 16 + 64
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    out[:tb] = to_dev(torch, hdr)
+    idx = ctx.index_alloc(data.size)
+    ctx.histogram(d_in)
+    total = ctx.encode_plan(d_in, d_code)
+    start = torch.tensor([8 * head], dtype=torch.int64, device="cuda")
+    end = ctx.encode_emit(d_in, d_code, out, start_bit=start, flags=8, index=idx)  # GHF_EMIT_LONG_CODES, no end mark
+    ctx.sync()
+    assert int(total.item()) == nbits and int(end[0].item()) == 8 * head + nbits
+    got = out[head : head + body.size].cpu().numpy()
+    assert np.array_equal(got, body), first_diff(got, body)
+    sbytes = head + body.size
+    # K7's long path with the side-car
+    back, nout = ctx.crs_decode(out, sbytes, left, d_tree, idx)
+    ctx.sync()
+    assert int(nout.item()) == data.size and np.array_equal(back[: data.size].cpu().numpy(), data)
+    ctx.index_free(idx)
+    # ... and K6 first (rows of stride 64 for depth > 32)
+    assert ctx.crs_decoded_size(out, sbytes, left, d_tree) == data.size
+    back2, n2 = ctx.crs_decode(out, sbytes, left, d_tree, None, cap=data.size + 64)
+    ctx.sync()
+    assert int(n2.item()) == data.size and np.array_equal(back2[: data.size].cpu().numpy(), data)
