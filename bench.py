@@ -557,9 +557,13 @@ def main():
         cx = ctxs[0]
         cx.use_stream(main)
         flags = local_flags  # (N > 1: the shard as a whole stream -- the kernels' own time does not depend on the collectives)
+        # N > 1: the sets' output buffers hold exactly this rank's part of the JOB's stream (ghf_shard_bytes); the shard as a
+        # stream of its own (own header, own code) needs the static bound
+        own_out = ctx.empty_u8(bound) if world > 1 else None
         for r in range(reps):
             b = sets[r % NSETS]
             b.index.flags = 0
+            o_buf, o_cap = (own_out, bound) if world > 1 else (b.out, b.bound)
 
             def ev(name, fn):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -571,9 +575,9 @@ def main():
             ev("histogram", lambda: cx.histogram(b.d_in, out=hists[0]))
             ev("build_code", lambda: cx.build_code(hists[0], codes[0]))
             ev("plan", lambda: cx.encode_plan(b.d_in, codes[0], total=t_total[0]))
-            ev("emit", lambda: cx.encode_emit(b.d_in, codes[0], b.out, flags=flags, index=b.index, end=b.end))
+            ev("emit", lambda: cx.encode_emit(b.d_in, codes[0], o_buf, flags=flags, index=b.index, end=b.end))
             cx.decode_prepare(codes[0])  # (k_build_decode_tables: a side-stream kernel of the pipeline, not part of K7)
-            ev("decode", lambda: cx.decode(b.out, b.bound, codes[0], b.index, d_out=b.dec, nbytes=t_nbytes))
+            ev("decode", lambda: cx.decode(o_buf, o_cap, codes[0], b.index, d_out=b.dec, nbytes=t_nbytes))
             torch.cuda.synchronize()  # one launch in flight at a time, and no host queueing effects in the events
         cx.sync()
         return {k: sum(a.elapsed_time(z) for a, z in v) / len(v) for k, v in acc.items()}

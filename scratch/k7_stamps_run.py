@@ -48,6 +48,9 @@ print(json.dumps({
     "sum_stamped_over_life": round(float(((a + b + c_ + d) / life).mean()), 3),
     "passes_by_wave_of_workgroup": [round(float(x), 1) for x in np_.reshape(256, 16).mean(axis=0)],
     "passes_per_workgroup_min_mean_max": [float(np_.reshape(256, 16).sum(axis=1).min()), float(np_.reshape(256, 16).sum(axis=1).mean()), float(np_.reshape(256, 16).sum(axis=1).max())],
+    "idle_behind_own_end_within_workgroup_cycles_mean_max": [float((endt.reshape(256, 16).max(axis=1, keepdims=True) - endt.reshape(256, 16)).mean()), float((endt.reshape(256, 16).max(axis=1, keepdims=True) - endt.reshape(256, 16)).max())],
+    "workgroup_span_cycles_mean": float((endt.reshape(256, 16).max(axis=1) - begin.reshape(256, 16).min(axis=1)).mean()),
+    "idle_by_wave_slot": [round(float(x), 0) for x in (endt.reshape(256, 16).max(axis=1, keepdims=True) - endt.reshape(256, 16)).mean(axis=0)],
     "passes_by_xcd": [round(float(x), 1) for x in np_.reshape(32, 8, 16).sum(axis=2).mean(axis=0)],
     "decode_cycles_per_pass_by_wave_of_workgroup": [round(float(x), 0) for x in (b.reshape(256, 16).sum(axis=0) / np_.reshape(256, 16).sum(axis=0))],
     "wait_cycles_per_pass_by_wave_of_workgroup": [round(float(x), 0) for x in (a.reshape(256, 16).sum(axis=0) / np_.reshape(256, 16).sum(axis=0))]}))
