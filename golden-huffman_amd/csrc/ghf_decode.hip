@@ -609,8 +609,10 @@ __global__ __launch_bounds__(kDec7Threads) void k_decode(DecParams P) {
   // tables are copied in, which hides its round trip.
   const uint32_t nwaves = gridDim.x * kDec7Waves;
   const uint32_t wid = blockIdx.x * kDec7Waves + (uint32_t)wave;
-  const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;  // every class needs at least one workgroup
-  const uint32_t cls = blockIdx.x % ncls;
+  // A class's workgroups are spread over all eight XCDs (consecutive workgroups go to consecutive XCDs): a class is a
+  // fixed share of the groups, and an XCD that runs slower than the others would otherwise finish its classes last.
+  const uint32_t ncls = gridDim.x < 16u ? 1u : (gridDim.x < 128u ? gridDim.x >> 3 : 16u);  // every class needs at least one workgroup
+  const uint32_t cls = (blockIdx.x >> 3) % ncls;
   uint32_t* const my_ticket = &P.dt->ticket[cls * 32];
   auto claim_issue = [&](unsigned int count) -> unsigned int {  // the atomic's return value stays in a VGPR until claim_group() needs it, a pass later
     unsigned int t = 0;

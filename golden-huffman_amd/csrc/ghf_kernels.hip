@@ -74,8 +74,10 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
   const uint32_t nfullchunks = (uint32_t)(n / chunk);
   const bool fast = V >= 4u && (chunk32 & 4095u) == 0 && (((uintptr_t)in) & 15u) == 0 && nfullchunks > 0;
   if (fast) {
-    const uint32_t ncls = gridDim.x < 16u ? gridDim.x : 16u;
-    const uint32_t cls = blockIdx.x % ncls;
+    // (a class's workgroups sit on all eight XCDs -- consecutive workgroups go to consecutive XCDs -- so that no XCD is
+    //  tied to a fixed share of the chunks; see k_decode)
+    const uint32_t ncls = gridDim.x < 16u ? 1u : (gridDim.x < 128u ? gridDim.x >> 3 : 16u);
+    const uint32_t cls = (blockIdx.x >> 3) % ncls;
     unsigned long long* tick = acc + 32 * 256 + 16 + cls * 16;
     // the first two chunks of a workgroup are fixed, so its first loads go out before any counter has answered;
     // tickets number the chunks behind those 2 * gridDim.x

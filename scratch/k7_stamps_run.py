@@ -51,6 +51,12 @@ print(json.dumps({
     "idle_behind_own_end_within_workgroup_cycles_mean_max": [float((endt.reshape(256, 16).max(axis=1, keepdims=True) - endt.reshape(256, 16)).mean()), float((endt.reshape(256, 16).max(axis=1, keepdims=True) - endt.reshape(256, 16)).max())],
     "workgroup_span_cycles_mean": float((endt.reshape(256, 16).max(axis=1) - begin.reshape(256, 16).min(axis=1)).mean()),
     "idle_by_wave_slot": [round(float(x), 0) for x in (endt.reshape(256, 16).max(axis=1, keepdims=True) - endt.reshape(256, 16)).mean(axis=0)],
+    "workgroup_span_by_xcd_mean": [round(float(x), 0) for x in (endt.reshape(32, 8, 16).max(axis=2) - begin.reshape(32, 8, 16).min(axis=2)).mean(axis=0)],
+    "workgroup_span_by_xcd_max": [round(float(x), 0) for x in (endt.reshape(32, 8, 16).max(axis=2) - begin.reshape(32, 8, 16).min(axis=2)).max(axis=0)],
+    "workgroup_span_percentiles": [round(float(x), 0) for x in np.percentile(endt.reshape(256, 16).max(axis=1) - begin.reshape(256, 16).min(axis=1), [0, 10, 50, 90, 100])],
+    "latest_workgroups_by_xcd(blockIdx, begin, end, passes; cycles from the XCD's first begin)": [
+        sorted([(int(b), float(begin.reshape(256, 16)[b].min() - begin.reshape(256, 16)[x::8].min()), float(endt.reshape(256, 16)[b].max() - begin.reshape(256, 16)[x::8].min()), float(np_.reshape(256, 16)[b].sum())) for b in range(x, 256, 8)], key=lambda t: -t[2])[:3] for x in range(8)],
+    "workgroup_begin_offsets_by_xcd_sorted": [sorted(int(v) for v in (begin.reshape(256, 16)[x::8].min(axis=1) - np.median(begin.reshape(256, 16)[x::8].min(axis=1)))) for x in range(8)],
     "passes_by_xcd": [round(float(x), 1) for x in np_.reshape(32, 8, 16).sum(axis=2).mean(axis=0)],
     "decode_cycles_per_pass_by_wave_of_workgroup": [round(float(x), 0) for x in (b.reshape(256, 16).sum(axis=0) / np_.reshape(256, 16).sum(axis=0))],
     "wait_cycles_per_pass_by_wave_of_workgroup": [round(float(x), 0) for x in (a.reshape(256, 16).sum(axis=0) / np_.reshape(256, 16).sum(axis=0))]}))
