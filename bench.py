@@ -664,12 +664,16 @@ def main():
             # the decode path a stream WITHOUT side-car takes (a .crs2 the reference wrote; what Decompressor<...>::decompress()
             # of the C++ host layer runs): K6 rebuilds the side-car on the GPU, then K7.  Host wall time: K6 looks at a
             # convergence word from the host a few times.
-            cx.decode(b.out, comp_bytes, codes[0], None, d_out=b.dec, cap=n, nbytes=t_nbytes)
+            # (THIS buffer's stream length: comp_bytes is another set's, a few hundred bytes more or less -- stale bytes behind
+            #  the end mark are legal input, but K6 then iterates over a tail nobody will read: what round 3's and this round's
+            #  first "4 GiB Zipf: 45..59 ms" were)
+            own_bytes = int(b.end[1].item())
+            cx.decode(b.out, own_bytes, codes[0], None, d_out=b.dec, cap=n, nbytes=t_nbytes)
             torch.cuda.synchronize()
             reps = 5
             tf0 = time.perf_counter()
             for _ in range(reps):
-                cx.decode(b.out, comp_bytes, codes[0], None, d_out=b.dec, cap=n, nbytes=t_nbytes)
+                cx.decode(b.out, own_bytes, codes[0], None, d_out=b.dec, cap=n, nbytes=t_nbytes)
             torch.cuda.synchronize()
             tf = (time.perf_counter() - tf0) / reps
             cx.sync()

@@ -36,7 +36,7 @@ struct ghf_ctx {
   const ghf_code* dt_code = nullptr;  // ghf_decode_prepare() built d_dt from these tables; consumed by the next ghf_decode
   uint64_t* d_totals = nullptr;  // [totals_cap] per-rank body bits (ghf_encode_sharded)
   int totals_cap = 0;
-  uint64_t* d_u64 = nullptr;    // [16] scratch scalars: 0 total_bits, 1..2 end, 3 n_symbols, 4 eof_sub, 5 changed, 6 start bit (.crs), 8 landing
+  uint64_t* d_u64 = nullptr;    // [16] scratch scalars: 0 total_bits, 1..2 end, 3 n_symbols, 4 eof_sub, 6 start bit (.crs), 8 landing, 9 changed + count, 10 first moved (inverted)
   uint64_t* h_u64 = nullptr;    // [16] pinned mirror
   // K6 workspace (foreign streams)
   void* d_sync = nullptr;
@@ -640,7 +640,8 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
   p.cnt = reinterpret_cast<uint32_t*>(ws + o_cnt);
   p.eof = ws + o_eof;
   p.tile_sum = reinterpret_cast<uint64_t*>(ws + o_tile);
-  p.changed = reinterpret_cast<uint32_t*>(c->d_u64 + 5);
+  p.changed = reinterpret_cast<uint32_t*>(c->d_u64 + 9);
+  p.moved_first_inv = reinterpret_cast<unsigned long long*>(c->d_u64 + 10);
   p.eof_sub = c->d_u64 + 4;
   GHF_HIP(c, hipMemsetAsync(p.start, 0, (p.nsub + 1) * 2, c->stream));
   if (first_start) launch_store_u64(reinterpret_cast<uint64_t*>(p.start), nullptr, first_start, c->stream);  // start[0] (the three
@@ -671,24 +672,38 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
       // (behind the deterministic scan the first pass only has to CONFIRM the boundaries: one pass, not a batch)
       const int nb = (scanned && passes == 0) ? 1 : kBatch;
       for (int b = 0; b < nb; ++b) {
-        GHF_HIP(c, hipMemsetAsync(p.changed, 0, 8, c->stream));
+        GHF_HIP(c, hipMemsetAsync(p.changed, 0, 16, c->stream));  // flag, count, first (inverted)
         launch_sync_pass(p, c->stream);
       }
       passes += nb;
       launch_store_u64(p.eof_sub, nullptr, p.nsub, c->stream);  // "none found"; k_sync_eof takes the minimum
       launch_sync_counts(p, c->d_u64 + 3, c->stream);
       launch_load_u16(c->d_u64 + 8, p.start + p.nsub, c->stream);
-      GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 3, c->d_u64 + 3, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      GHF_HIP(c, hipMemcpyAsync(c->h_u64 + 3, c->d_u64 + 3, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       GHF_HIP(c, hipStreamSynchronize(c->stream));
-      if ((uint32_t)c->h_u64[5] == 0) break;
+#ifdef GHF_K6_TRACE  // (scratch/build_variant.sh k6trace -DGHF_K6_TRACE: what every batch of passes left behind)
+      fprintf(stderr, "[k6] nsub %llu passes %llu scanned %d flag %u moved~%llu first %llu eof_sub %llu\n", (unsigned long long)p.nsub,
+              (unsigned long long)passes, (int)scanned, (unsigned)c->h_u64[9], (unsigned long long)((c->h_u64[9] >> 32) * 256),
+              (unsigned long long)~c->h_u64[10], (unsigned long long)c->h_u64[4]);
+#endif
+      if ((uint32_t)c->h_u64[9] == 0) break;
+      // .crs2: settled IN FRONT OF THE END MARK is settled.  No landing at or before the first end mark's subsequence moved
+      // in the batch's last pass -> every boundary up to it is a fixed point, the mark is the stream's (the first one, and
+      // real).  What lies behind it (a buffer longer than its stream: stale bytes) may go on moving for ever.
+      if (!no_eof && mode != 2 && c->h_u64[10] != 0 && ~c->h_u64[10] >= c->h_u64[4] && c->h_u64[4] < p.nsub) break;
+      const uint64_t moved = (c->h_u64[9] >> 32) * 256;  // boundaries the batch's last pass moved (sampled: every 256th group)
       // Not settled.  A boundary that is still moving travels ONE subsequence to the right per pass, and a pass in which
       // little moved costs little (a wave whose 64 subsequences are current skips them), so a few more batches are cheaper
       // than the deterministic scan over the whole stream -- which long streams of a quickly synchronising code otherwise
       // fall into because SOME stretch among their millions of subsequences needs a fifth pass (4 GiB Zipf: 44 ms with
       // the scan after the first batch, see profiles/r04/foreign_4GiB.txt).  Codes that do not settle in kScanAfter passes
       // (long runs of one value, near-fixed-length codes the caller did not announce) get the scan then.
-      constexpr uint64_t kScanAfter = 16;
-      if (!scanned && passes >= kScanAfter) {
+      // What decides is HOW MUCH still moves: a few stragglers (one stretch in a 4 GiB Zipf stream needs 17..20 passes,
+      // whichever seed) are followed for up to kScanAfterFew passes; a stream in which boundaries still move everywhere
+      // after two batches is not going to settle by itself.
+      constexpr uint64_t kScanAfterMany = 8, kScanAfterFew = 64;
+      const uint64_t few = p.nsub >> 10 > 4096 ? p.nsub >> 10 : 4096;
+      if (!scanned && (passes >= kScanAfterFew || (passes >= kScanAfterMany && moved > few))) {
         launch_sync_scan(p, ws + o_scan, fn_stride, first_start, c->stream);
         scanned = true;
       }

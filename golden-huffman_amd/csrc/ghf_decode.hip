@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
     const uint64_t sub = g * 64 + lane;
     const bool valid = sub < P.nsub;
     uint32_t st = 0;
-    bool work = false;
+    bool work = false, moved = false;
     if (valid) {
       st = P.start[sub];
       work = P.used[sub] != st;
@@ -1182,11 +1182,24 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
         if (P.start[sub + 1] != land) {
           P.start[sub + 1] = land;
           *P.changed = 1;
+          moved = true;
         }
       }
       // a PIECE of a stream (mode 2, multi-GPU decode): the last code may run into the next piece's bytes (they are
       // there as look-ahead); where it ends is the next piece's first code boundary
       if (P.no_eof == 2u && sub + 1 == P.nsub) P.start[P.nsub] = eof ? (uint16_t)0xFFFF : (uint16_t)(pos - limit);
+    }
+    // ... and roughly how MANY boundaries moved, for the driver's choice between more passes and the deterministic scan:
+    // every 256th group adds its count to the word behind the flag (all groups would be three million atomics on one
+    // address in a 4 GiB stream's first pass)
+    const uint64_t mv = __ballot(moved);
+    if (mv && lane == 0) {
+      if ((g & 255u) == 0) atomicAdd(P.changed + 1, (uint32_t)__builtin_popcountll(mv));
+      // ... and WHERE the first of them is: nothing in front of the stream's end mark moving any more is all the driver
+      // needs (a buffer may go on behind its end mark -- stale bytes -- and those never have to settle).  Stored inverted
+      // so that "none" is the zero the flag's memset leaves; the read in front keeps the atomics to the few that improve it
+      const unsigned long long inv = ~(g * 64 + (uint64_t)__builtin_ctzll(mv));
+      if (inv > __hip_atomic_load(P.moved_first_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(P.moved_first_inv, inv);
     }
   }
   };

@@ -129,7 +129,8 @@ struct SyncParams {
   uint16_t* used;      // [nsub]     the guess the stored result was computed from (0xFFFF = none yet)
   uint32_t* cnt;       // [nsub]     codes starting in the subsequence (up to an end mark)
   uint8_t* eof;        // [nsub]     the end mark was decoded in this subsequence
-  uint32_t* changed;   // some guess moved during the pass
+  uint32_t* changed;   // [0] some guess moved during the pass; [1] how many did, roughly (every 256th group counts)
+  unsigned long long* moved_first_inv;  // ~(smallest subsequence whose landing moved during the pass); 0: none (sits behind `changed`)
   uint64_t* eof_sub;   // first subsequence holding the end mark
   uint64_t* tile_sum;  // [nsub / 256 + 2] symbols per tile, then (in place) their exclusive scan
 };
