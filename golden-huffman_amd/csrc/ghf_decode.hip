@@ -372,13 +372,12 @@ __device__ __forceinline__ uint32_t dec_long_entry_at(const LT& L, uint64_t W, u
 // corrupt).  Every variant ends in the same four stores (the callers' copy-out), so that the compiler can count the kernel's
 // memory operations whichever variant runs.
 //
-// A LOOP, not 64 unrolled lookups: round 3's (and this round's first) straight-line form made a pass 8..9 KB of code, and
-// instruction fetch is what bounds such code on this part -- a loop body beyond ~4 KB issues at HALF the rate of a short
-// one (scratch/ifetch.hip, profiles/r04/ifetch.txt: 2.7 -> 5.4 cycles per 8-byte VALU instruction and SIMD with four waves
-// on it; one wave alone 5 -> 10): with 10..12 VALU instructions per symbol that, not the LDS round trip in a lane's chain
-// and not the VALU rate, set K7's time ("instruction count is not time" of round 3 was this).  The body is one period of
-// the refill pattern -- lcm(4, K) symbols, at most 12 = about 0.8 KB -- and the decoded dwords go to out[] through the
-// uniform loop counter (s_set_gpr_idx: no scratch).
+// A LOOP, not 64 unrolled lookups: the straight-line form of round 3 (and of this round's first build) made a pass 8..9 KB of
+// code and kept 39 registers more alive.  (Code size itself is NOT what that costs: loop bodies up to 16 KB issue at the full
+// rate, scratch/ifetch2.hip, profiles/r04/experiments/ifetch2.txt -- the "cliff at 4 KB" an earlier micro-benchmark showed was a
+// macro that repeated twice as often as its name said.)  The body is one period of the refill pattern -- lcm(4, K) symbols,
+// at most 12 = about 0.8 KB -- and the decoded dwords go to out[] through the uniform loop counter (s_set_gpr_idx: no
+// scratch); with 89 registers a K7 workgroup shares its CU with the one-wave code build of a later step.
 typedef uint32_t DecOut __attribute__((ext_vector_type(16)));  // a lane's 64 decoded bytes: a register TUPLE, so that out[t] with a
                                                                 // uniform t is an indexed register move and never memory
 template <int K, bool LONG, typename LT>
