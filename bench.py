@@ -313,14 +313,17 @@ def main():
     mains = [main] + [torch.cuda.Stream(priority=-1) for _ in range(NMAIN - 1)]
     # Steps in flight.  Steady state needs three; more let the main stream count the first inputs while the FIRST step's
     # one-wave code build (nothing to overlap it with at the start of a run) is still going.
+    FRONT_FIRST = os.environ.get("GHF_BENCH_FRONT_FIRST", "1") == "1"
+    RAMP0 = int(os.environ.get("GHF_BENCH_RAMP0", "3"))
     DEPTH = int(os.environ.get("GHF_BENCH_DEPTH", "8"))
     ahead = DEPTH - 1
-    # Side streams.  N = 1: two (one would serialise the code builds of consecutive steps: that one-wave kernel then paces
-    # the pipeline).  N > 1: ONE, and one communicator -- collectives are then issued in strict step order on one stream on
+    # Side streams.  N = 1: four.  A step's side chain -- code build 0.26 ms alone and 0.35 between the streaming kernels,
+    # chunk pricing, decode tables: 0.5 ms -- has to keep up with a main pipeline of 0.29 ms per step: one side stream paces
+    # the run outright, two still did (865 GB/s; three 900, four 922, eight 920).  N > 1: ONE, and one communicator -- collectives are then issued in strict step order on one stream on
     # every rank, which is the only order RCCL guarantees to match up across ranks (two communicators' kernels may be
     # launched in different orders on different ranks: a deadlock that needs all 8 GPUs to show).  GHF_BENCH_NSIDE
     # overrides (one communicator per side stream).
-    NSIDE = int(os.environ.get("GHF_BENCH_NSIDE", "2" if world == 1 else "1"))
+    NSIDE = int(os.environ.get("GHF_BENCH_NSIDE", "4" if world == 1 else "1"))
     sides = [torch.cuda.Stream(priority=0) for _ in range(NSIDE)]
     ctxs = [ctx] + [ghf.Context(local_rank) for _ in range(DEPTH - 1)]
     hists = [torch.empty(ghf.NSYM, dtype=torch.int64, device="cuda") for _ in range(DEPTH)]
@@ -418,13 +421,26 @@ def main():
 
         def run(self, K, record):
             rec_of = lambda j: record and (j % 4 == 1 or K <= 4)  # events on every 4th step: keeps the host ahead of the GPU
-            for j in range(min(ahead, K)):
-                self.front(j, rec_of(j))
+            # The look-ahead is RAMPED: three steps' fronts first (their enqueueing takes the host as long as the first code
+            # build takes the GPU), then the first emit / decode, then two fronts per step until the host is `ahead` steps
+            # in front.  Enqueueing all `ahead` fronts first left the GPU with nothing but eight histograms for the first
+            # millisecond of a run (0.1 ms of host work per front: scratch/trace_timeline.py) -- 0.5 ms per run, 8 % of a
+            # 20-step one.
+            nf = 0  # fronts enqueued
+            while nf < min(ahead, RAMP0, K):
+                self.front(nf, rec_of(nf))
+                nf += 1
             for i in range(K):
                 k = i % DEPTH
                 cx, c, b = ctxs[k], codes[k], sets[i % NSETS]
-                if i + ahead < K:
-                    self.front(i + ahead, rec_of(i + ahead))
+                while nf <= i:  # (only with GHF_BENCH_DEPTH=1: no look-ahead at all)
+                    self.front(nf, rec_of(nf))
+                    nf += 1
+                if FRONT_FIRST:
+                    for _ in range(2):
+                        if nf < min(K, i + 1 + ahead):
+                            self.front(nf, rec_of(nf))
+                            nf += 1
                 mstream = mains[i % NMAIN]
                 mstream.wait_event(ev_ready[k])
                 cx.use_stream(mstream)
@@ -434,6 +450,10 @@ def main():
                 self.timed("emit", i, rec_of(i), mstream, lambda: cx.encode_emit(b.d_in, c, b.out, start_bit=start_bit, flags=flags, index=b.index, end=b.end))
                 self.timed("decode", i, rec_of(i), mstream, lambda: cx.decode(b.out, b.bound, c, b.index, d_out=b.dec, nbytes=t_nbytes))
                 ev_done[k].record(mstream)
+                for _ in range(0 if FRONT_FIRST else 2):  # (behind the step's own kernels: its emit must not wait for the host to enqueue other steps' fronts)
+                    if nf < min(K, i + 1 + ahead):
+                        self.front(nf, rec_of(nf))
+                        nf += 1
 
         def measure(self, K, barrier):
             """time exactly K steps: barrier + synchronize on both sides"""
