@@ -361,6 +361,7 @@ def main():
         def __init__(self, sharded, comms):
             self.sharded, self.comms = sharded, comms
             self.ev_log = []  # (name, start_event, end_event)
+            self.host_front_s, self.host_fronts = 0.0, 0  # host time spent enqueueing fronts (diagnostic: must stay well below the step time)
 
         def timed(self, name, step, record, stream, fn):
             wd.enter("%s of step %d" % (name, step))
@@ -383,6 +384,14 @@ def main():
         def front(self, i, record):
             """step i up to the point where its emit can start: K1 on the main stream; all-reduce, K2/K3, K4, decode
             tables, all-gather on a side stream."""
+            th0 = time.perf_counter()
+            try:
+                self._front(i, record)
+            finally:
+                self.host_front_s += time.perf_counter() - th0
+                self.host_fronts += 1
+
+        def _front(self, i, record):
             k = i % DEPTH
             cx, h, c, side, b = ctxs[k], hists[k], codes[k], sides[i % NSIDE], sets[i % NSETS]
             comm = self.comms[i % NSIDE] if self.comms else None
@@ -639,6 +648,7 @@ def main():
                        "buffer_sets": NSETS, "side_streams": NSIDE, "histogram_stream": "own" if pre is not main else "main", "communicators": len(comms) if comms else 0,
                        "pipeline": "steps software-pipelined, up to %d in flight (one ghf context each, %d side stream(s)), rotating over %d sets of {input, output, decoded, side-car} buffers: main stream = histogram of step i+%d, emit + decode of step i%s; side stream(s), ahead of the main one = histogram all-reduce, one-wave code build, chunk pricing, decode tables, offset all-gather.  stage_ms = events inside the timed region (kernels of different streams share the GPU); stage_ms_alone and roofline = a separate pass behind it, one kernel at a time" % (DEPTH, NSIDE, NSETS, DEPTH - 1, " (even and odd steps on two main streams)" if NMAIN > 1 else "")},
             "main_streams": NMAIN,
+            "host_enqueue_ms_per_front": round(job.host_front_s * 1e3 / max(job.host_fronts, 1), 4),
             "encode_GBps": round(n * world / (enc_ms * 1e-3) / 1e9, 3), "decode_GBps": round(n * world / (stage_alone["decode"] * 1e-3) / 1e9, 3),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_alone": {k: round(v, 4) for k, v in stage_alone.items()},
