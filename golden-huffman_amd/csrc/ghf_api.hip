@@ -643,11 +643,23 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
   p.changed = reinterpret_cast<uint32_t*>(c->d_u64 + 9);
   p.moved_first_inv = reinterpret_cast<unsigned long long*>(c->d_u64 + 10);
   p.eof_sub = c->d_u64 + 4;
-  GHF_HIP(c, hipMemsetAsync(p.start, 0, (p.nsub + 1) * 2, c->stream));
-  if (first_start) launch_store_u64(reinterpret_cast<uint64_t*>(p.start), nullptr, first_start, c->stream);  // start[0] (the three
-                                                                                                          // guesses behind it stay 0)
-  GHF_HIP(c, hipMemsetAsync(p.used, 0xFF, p.nsub * 2, c->stream));
-  GHF_HIP(c, hipMemsetAsync(p.eof, 0, p.nsub, c->stream));
+  // `start`, `used`, `eof` (11 bytes per KiB of stream: 3 + 3 + 1.5 MB at 256 MiB) are not cleared when the fixed-point passes
+  // come first: the first k_sync_pass of the call finds every subsequence unworked and every guess 0 because its parameters
+  // say so (SyncParams::first), and writes all three arrays whole.  (Round 3 queued three memsets, 60 us at 256 MiB in front
+  // of a 1 ms job.)
+  const bool scan_first = prefer_scan && first_start < ((max_len_hint >= 1 && max_len_hint <= 16) ? 16u : (max_len_hint > 32 ? 64u : 32u));
+  if (scan_first) {
+    // (the scan's kernels write the guesses they derive -- and, for the subsequences whose class walk already is the whole
+    //  answer, the results too: `used` must say "nothing yet" for all the others)
+    GHF_HIP(c, hipMemsetAsync(p.start, 0, (p.nsub + 1) * 2, c->stream));
+    if (first_start) launch_store_u64(reinterpret_cast<uint64_t*>(p.start), nullptr, first_start, c->stream);  // start[0]
+    GHF_HIP(c, hipMemsetAsync(p.used, 0xFF, p.nsub * 2, c->stream));
+    GHF_HIP(c, hipMemsetAsync(p.eof, 0, p.nsub, c->stream));
+  } else {
+    launch_store_u64(reinterpret_cast<uint64_t*>(p.start), nullptr, first_start, c->stream);  // start[0] (k_sync_pass stores start[1 ..])
+  }
+  p.first = scan_first ? 0u : 3u;
+  p.first_start = first_start;
   // passes until no boundary guess moves (self-synchronisation: a handful of passes in practice).  They are queued in
   // batches; behind every batch the counts (first end mark, symbols per tile, their scan) and the landing bit are queued as
   // well, and the host reads {symbols, end-mark subsequence, "something moved", landing} in ONE round trip: a stream that has
@@ -674,6 +686,7 @@ static int rebuild_index_at(ghf_ctx* c, const uint8_t* d_stream, size_t stream_b
       for (int b = 0; b < nb; ++b) {
         GHF_HIP(c, hipMemsetAsync(p.changed, 0, 16, c->stream));  // flag, count, first (inverted)
         launch_sync_pass(p, c->stream);
+        p.first = 0;
       }
       passes += nb;
       launch_store_u64(p.eof_sub, nullptr, p.nsub, c->stream);  // "none found"; k_sync_eof takes the minimum

@@ -1132,8 +1132,8 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
     uint32_t st = 0;
     bool work = false, moved = false;
     if (valid) {
-      st = P.start[sub];
-      work = P.used[sub] != st;
+      st = (P.first & 2u) ? (sub == 0 ? P.first_start : 0u) : P.start[sub];
+      work = (P.first & 1u) ? true : P.used[sub] != st;
     }
     if (!__ballot(work)) continue;  // the whole wave's results are still current
     wave_sync();
@@ -1176,7 +1176,19 @@ __global__ __launch_bounds__(kK6Threads, 4) void k_sync_pass(SyncParams P) {
       P.cnt[sub] = count;
       P.eof[sub] = eof ? 1 : 0;
       P.used[sub] = (uint16_t)st;
-      if (!eof && pos >= sub_hi && sub + 1 < P.nsub) {
+      if (P.first & 2u) {
+        // the launch that fills `start`: every subsequence stores its neighbour's guess, 0 ("nothing known") included
+        if (sub + 1 < P.nsub) {
+          const uint16_t land = (!eof && pos >= sub_hi) ? (uint16_t)(pos - sub_hi) : (uint16_t)0;
+          P.start[sub + 1] = land;
+          if (land) {
+            *P.changed = 1;
+            moved = true;
+          }
+        } else if (P.no_eof != 2u) {
+          P.start[P.nsub] = 0;  // (the landing slot: a piece's last subsequence stores it below)
+        }
+      } else if (!eof && pos >= sub_hi && sub + 1 < P.nsub) {
         const uint16_t land = (uint16_t)(pos - sub_hi);
         if (P.start[sub + 1] != land) {
           P.start[sub + 1] = land;

@@ -129,6 +129,10 @@ struct SyncParams {
   uint16_t* used;      // [nsub]     the guess the stored result was computed from (0xFFFF = none yet)
   uint32_t* cnt;       // [nsub]     codes starting in the subsequence (up to an end mark)
   uint8_t* eof;        // [nsub]     the end mark was decoded in this subsequence
+  uint32_t first;      // k_sync_pass only.  bit 0: every subsequence has work (`used`, `eof` hold nothing yet: the launch that
+                       // writes them all needs no memset in front of it); bit 1: every guess is 0 except subsequence 0's
+                       // (`start` holds nothing yet either; this launch writes start[1 .. nsub])
+  uint32_t first_start;  // subsequence 0's guess (bit 1 of `first`)
   uint32_t* changed;   // [0] some guess moved during the pass; [1] how many did, roughly (every 256th group counts)
   unsigned long long* moved_first_inv;  // ~(smallest subsequence whose landing moved during the pass); 0: none (sits behind `changed`)
   uint64_t* eof_sub;   // first subsequence holding the end mark
