@@ -190,7 +190,9 @@ int ghf_parse_header(const uint8_t* h_stream, size_t n, ghf_code* code, size_t* 
  * d_stream is the buffer an emit call wrote (a whole .crs2 image, or one shard's GHF_EMIT_REBASE buffer)
  * and index the side-car that call filled: the decode is then block-parallel (length-indexed canonical
  * table in LDS).  Without one (index == NULL, e.g. a .crs2 written by the reference; d_stream must then
- * be a whole .crs2 image) the index is first rebuilt on the GPU from the bit stream.
+ * be a whole .crs2 image) the index is first rebuilt on the GPU from the bit stream.  stream_bytes may exceed the
+ * stream: the first end mark ends it, as in the reference's decoders (canonical_huff_encoder.cc:404), and what lies
+ * behind it is neither decoded nor waited for.
  * d_code may come from anywhere: before anything is decoded the tables are checked on the device to be a
  * complete prefix code (Kraft equality, lengths within [min_len, max_len], first codes that fit their length,
  * start positions inside symbol[]; the one-symbol code of GHF_EMPTY_OK is the exception) -- if not,
