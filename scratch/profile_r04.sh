@@ -42,17 +42,19 @@ done
 cd $R
 echo "== the other 256 MiB inputs"
 for KIND in zipf sym16; do
-  python3 bench.py --steps 100 --kind $KIND --no-configs --no-cpu-baseline > $O/bench_256MiB_$KIND.json 2> /dev/null
+  python3 bench.py --steps 100 --kind $KIND --no-configs --no-cpu-baseline > $O/bench_256MiB_$KIND.json 2> $O/bench_256MiB_$KIND.err
 done
 for KIND in uniform zipf; do
-  python3 bench.py --mib 4096 --steps 40 --warmup 2 --kind $KIND --no-configs --no-cpu-baseline > $O/bench_4GiB_$KIND.json 2> /dev/null
+  python3 bench.py --mib 4096 --steps 40 --warmup 2 --kind $KIND --no-configs --no-cpu-baseline > $O/bench_4GiB_$KIND.json 2> $O/bench_4GiB_$KIND.err
 done
 fi
 if [ $PART = all ] || [ $PART = C ]; then
 cd $R
 echo "== stream layouts"
-GHF_BENCH_MAINS=1 python3 bench.py --steps 200 --no-configs --no-cpu-baseline > $O/bench_one_main_stream.json 2> /dev/null
-GHF_BENCH_K1_STREAM=1 python3 bench.py --steps 200 --no-configs --no-cpu-baseline > $O/bench_two_mains_k1_stream.json 2> /dev/null
+GHF_BENCH_MAINS=1 python3 bench.py --steps 200 --no-configs --no-cpu-baseline > $O/bench_one_main_stream.json 2> $O/bench_one_main_stream.err
+GHF_BENCH_NSIDE=2 python3 bench.py --steps 200 --no-configs --no-cpu-baseline > $O/bench_two_side_streams.json 2> $O/bench_two_side_streams.err
+GHF_BENCH_NSIDE=1 python3 bench.py --steps 200 --no-configs --no-cpu-baseline > $O/bench_one_side_stream.json 2> $O/bench_one_side_stream.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-configs --no-cpu-baseline > $O/bench_20_steps.json 2> $O/bench_20_steps.err
 echo "== memory microbenchmark"
 timeout -k 10 300 ./scratch/membench > $O/membench.txt 2>&1
 echo "== file to file"
@@ -60,6 +62,7 @@ timeout -k 10 600 python3 scratch/file_perf.py 4 uniform zipf > $O/file_perf.log
 timeout -k 10 300 python3 scratch/file_trace_reuse.py uniform > $O/pipe_trace_reuse_uniform.log 2>&1
 timeout -k 10 300 python3 scratch/file_trace_reuse.py zipf > $O/pipe_trace_reuse_zipf.log 2>&1
 fi
+# (no GPU process's stderr goes to /dev/null: every run leaves its .err beside its .json)
 # raw per-dispatch traces are large; keep stats and counter files only
 find $O -name '*kernel_trace.csv' -size +6M -delete
 find $O -name '*.db' -delete
