@@ -372,9 +372,47 @@ struct EmitGeom {      // wave-uniform facts about the stream
   int max_len;
 };
 
+constexpr int kEmitNB = 4;  // tile buffers = tiles per trip of the main loop = one side-car block
+
+// Everything a chunk's start needs from memory, requested at once, oldest first -- the chunk's bit offset, the two symbols
+// per lane in front of it, its first two tiles -- and requested at KERNEL ENTRY, in front of the status check, the code
+// tables' trip into LDS and their barriers: none of it depends on them (kernel arguments only), and every workgroup of a
+// 256 MiB launch is in the launch's first round, so the five dependent round trips of the old prologue (status, max_len,
+// table words, chunk offset, first tiles) were 5 % of the launch for every wave.
+constexpr int kEmitPreNB = 2;  // tiles requested at kernel entry (all four would cost the packers two spilled registers)
+struct EmitPre {
+  uint64_t chunk_off;
+  uint32_t prev0, prev1;
+  uint4 buf[kEmitPreNB];
+};
+__device__ __forceinline__ void emit_prefetch(const EmitParams& P, uint32_t c, int lane, EmitPre& R) {
+  R.chunk_off = 0;
+  R.prev0 = R.prev1 = 0;
+#pragma unroll
+  for (int j = 0; j < kEmitPreNB; ++j) R.buf[j] = make_uint4(0, 0, 0, 0);
+  if (c >= P.nchunks) return;
+  const uint64_t chunk = P.chunk;
+  const uint64_t sym0 = (uint64_t)c * chunk;
+  const uint64_t nsym = (P.n - sym0 < chunk) ? (P.n - sym0) : chunk;
+  const uint8_t* pin = P.in + sym0;
+  R.chunk_off = P.chunk_off[c];
+  if (c > 0) {
+    // the previous chunk's last 128 symbols (it is a full chunk, >= 4096 symbols), two per lane: a code has at least
+    // one bit, so they cover the <= 127 bits in front of this chunk that share its first unit
+    const uint8_t* pp = pin - 128 + 2 * lane;
+    R.prev0 = pp[0];
+    R.prev1 = pp[1];
+  }
+  if ((((uintptr_t)pin) & 15u) == 0 && nsym / kSymPerIter >= (uint64_t)kEmitNB) {
+    const uint4* pv = reinterpret_cast<const uint4*>(pin) + lane;
+#pragma unroll
+    for (int j = 0; j < kEmitPreNB; ++j) R.buf[j] = pv[j * 64];
+  }
+}
+
 template <int MODE>
 __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& G, uint32_t c, const uint32_t* tab,
-                                           uint32_t* flat, uint32_t* st, int lane) {
+                                           uint32_t* flat, uint32_t* st, int lane, const EmitPre& pre) {
   typedef EmitMode<MODE> M;
   constexpr bool WIDE = MODE == 0 || MODE == 4;  // the deposit-by-OR paths
   constexpr int NI = M::NI;
@@ -383,29 +421,20 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
   const uint64_t nsym = (P.n - sym0 < chunk) ? (P.n - sym0) : chunk;
   const uint8_t* pin = P.in + sym0;
   const bool aligned = (((uintptr_t)pin) & 15u) == 0;
-  // ---- everything this chunk's start needs from memory is requested at once, oldest first: the chunk's bit offset, the
-  // two symbols per lane in front of it, its first two tiles (three dependent round trips otherwise, per chunk)
-  const uint64_t chunk_off = P.chunk_off[c];
-  uint32_t prev0 = 0, prev1 = 0;
-  if (c > 0) {
-    // the previous chunk's last 128 symbols (it is a full chunk, >= 4096 symbols), two per lane: a code has at least
-    // one bit, so they cover the <= 127 bits in front of this chunk that share its first unit
-    const uint8_t* pp = pin - 128 + 2 * lane;
-    prev0 = pp[0];
-    prev1 = pp[1];
-  }
+  const uint64_t chunk_off = pre.chunk_off;
+  const uint32_t prev0 = pre.prev0, prev1 = pre.prev1;
   const uint64_t nfull = aligned ? (nsym / kSymPerIter) : 0;
   const uint4* pv = reinterpret_cast<const uint4*>(pin) + lane;
   // codes beyond 16 bits take the plain loop below (rare, and it keeps that instantiation free of spills); a side-car is
   // written whole or not at all
-  constexpr int NB = 4;  // tile buffers = tiles per trip of the main loop = one side-car block
+  constexpr int NB = kEmitNB;
   const bool streamed = !WIDE && nfull >= (uint64_t)NB && ((P.seg_bit != nullptr) == (P.chunk_bit != nullptr));
   uint4 buf[NB];
 #pragma unroll
-  for (int j = 0; j < NB; ++j) buf[j] = make_uint4(0, 0, 0, 0);
+  for (int j = 0; j < NB; ++j) buf[j] = j < kEmitPreNB ? pre.buf[j] : make_uint4(0, 0, 0, 0);  // (loaded whenever the chunk has four full, aligned tiles; only `streamed` reads them)
   if (streamed) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) buf[j] = pv[j * 64];
+    for (int j = kEmitPreNB; j < NB; ++j) buf[j] = pv[j * 64];
   }
   const uint64_t Pc = G.start_bit + chunk_off;
   WaveOut W;
@@ -579,11 +608,8 @@ __device__ __forceinline__ void emit_chunk(const EmitParams& P, const EmitGeom& 
 // `mine` = this kernel is the one that packs codes of this length (the other one of the pair leaves without a trace).
 __device__ __forceinline__ bool emit_begin(const EmitParams& P, EmitGeom& G, int* status0, bool long_kernel) {
   const int tid = threadIdx.x;
-  if (tid == 0) *status0 = *P.status;  // a previous stage failed -> uniform exit
-  __syncthreads();
-  if (*status0 != 0) return false;
+  if (tid == 0) *status0 = *P.status;  // a previous stage failed -> uniform exit (checked below: its round trip overlaps the others)
   G.max_len = P.code->max_len;
-  if ((G.max_len > 32) != long_kernel) return false;
   G.start_bit = P.d_start_bit ? *P.d_start_bit : 8ull * (1040ull + 8ull * (uint64_t)G.max_len);
   G.origin_byte = (P.flags & GHF_EMIT_REBASE) ? ((G.start_bit >> 7) << 4) : 0ull;
   // where the stream ends; does it fit?  (every workgroup computes the same answer from the same few words)
@@ -595,6 +621,9 @@ __device__ __forceinline__ bool emit_begin(const EmitParams& P, EmitGeom& G, int
   const uint64_t end_byte = ((end + 7) >> 3) - G.origin_byte;
   const uint64_t end_unit_bytes = (((end >> 7) + 1) << 4) - G.origin_byte;  // through the unit holding the end bit
   const bool fits = end_unit_bytes <= P.cap || (((end & 127u) == 0) && end_byte <= P.cap);
+  __syncthreads();
+  if (*status0 != 0) return false;  // (what was read above is then meaningless, and unused)
+  if ((G.max_len > 32) != long_kernel) return false;
   if (blockIdx.x == 0 && tid == 0) {
     if (!fits) latch_status(P.status, GHF_E_CAP);
     if (P.d_end) {
@@ -610,6 +639,21 @@ __global__ __launch_bounds__(kEmitThreads, 6) void k_emit(EmitParams P) {
   __shared__ __attribute__((aligned(16))) uint32_t stage[kEmitWaves * kStageWords];
   __shared__ int status0;
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell the compiler it is wave-uniform (SGPR)
+  const uint32_t c = blockIdx.x * kEmitWaves + wave;
+  // ---- every load of the prologue goes out here, before the first barrier: this wave's chunk start, this thread's table words
+  EmitPre pre;
+  emit_prefetch(P, c, lane, pre);
+  constexpr int kTabTrips = 1024 / kEmitThreads;
+  static_assert(1024 % kEmitThreads == 0, "table slots per thread");
+  uint32_t tcode[kTabTrips], tlen[kTabTrips];
+#pragma unroll
+  for (int k = 0; k < kTabTrips; ++k) {
+    const int sy = (tid + k * kEmitThreads) >> 2;
+    tcode[k] = P.code->codeword[sy];
+    tlen[k] = P.code->length[sy];
+  }
   EmitGeom G;
   if (!emit_begin(P, G, &status0, false)) {
     // codes beyond 32 bits are k_emit_long's (queued behind this kernel when the caller said GHF_EMIT_LONG_CODES);
@@ -623,9 +667,11 @@ __global__ __launch_bounds__(kEmitThreads, 6) void k_emit(EmitParams P) {
     // 4 slots per symbol, each 32 bytes of the symbol's 128-byte row: replicas 8 * (i & 3) .. (u32) or 4 * (i & 3) .. (u64).
     // The tables may be the caller's own: the packers below size their registers and the staging area by max_len.
     bool bad = G.max_len < 1;
-    for (int i = tid; i < 1024; i += kEmitThreads) {
+#pragma unroll
+    for (int k = 0; k < kTabTrips; ++k) {
+      const int i = tid + k * kEmitThreads;
       const int s = i >> 2;
-      const uint32_t code = P.code->codeword[s], len = P.code->length[s];
+      const uint32_t code = tcode[k], len = tlen[k];
       bad |= len > (uint32_t)G.max_len;
       uint4 v;
       if (!wide) {
@@ -643,15 +689,12 @@ __global__ __launch_bounds__(kEmitThreads, 6) void k_emit(EmitParams P) {
     }
   }
   __syncthreads();
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell the compiler it is wave-uniform (SGPR)
-  const uint32_t c = blockIdx.x * kEmitWaves + wave;
   if (c >= P.nchunks) return;
   uint32_t* const st = stage + wave * kStageWords;
-  if (G.max_len <= 9) emit_chunk<1>(P, G, c, tab, stage, st, lane);
-  else if (G.max_len <= 12) emit_chunk<2>(P, G, c, tab, stage, st, lane);
-  else if (!wide) emit_chunk<3>(P, G, c, tab, stage, st, lane);
-  else emit_chunk<0>(P, G, c, tab, stage, st, lane);
+  if (G.max_len <= 9) emit_chunk<1>(P, G, c, tab, stage, st, lane, pre);
+  else if (G.max_len <= 12) emit_chunk<2>(P, G, c, tab, stage, st, lane, pre);
+  else if (!wide) emit_chunk<3>(P, G, c, tab, stage, st, lane, pre);
+  else emit_chunk<0>(P, G, c, tab, stage, st, lane, pre);
 }
 
 // Codes of 33..64 bits (a .crs whose tree is deeper than 32).  Same chunks, same one-writer-per-unit layout, same
@@ -673,7 +716,9 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit_long(EmitParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t c = blockIdx.x * kEmitWaves + wave;
   if (c >= P.nchunks) return;
-  emit_chunk<4>(P, G, c, reinterpret_cast<const uint32_t*>(P.code), stage, stage + wave * kStageWords, lane);
+  EmitPre pre;
+  emit_prefetch(P, c, lane, pre);
+  emit_chunk<4>(P, G, c, reinterpret_cast<const uint32_t*>(P.code), stage, stage + wave * kStageWords, lane, pre);
 }
 
 void launch_emit(const EmitParams& p, hipStream_t s) {

@@ -41,11 +41,27 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
   __shared__ bool s_last;
   const uint32_t tid = threadIdx.x;
   const uint32_t rep = tid & 31u;
-  for (uint32_t i = tid; i < 256 * kHistRep; i += kHistThreads) lh[i] = 0;
-  __syncthreads();
   uint32_t prev = 0;
   unsigned long long total = 0;
   const uint64_t chunk = chunk32;
+  // the fast phase's first two vectors are requested BEFORE the counters are cleared: a workgroup's first HBM round trip
+  // hides behind the 32 KiB of LDS stores and the barrier instead of following them
+  const uint32_t V = chunk32 >> 12;  // vectors per thread per chunk (256 threads x 16 B = 4 KiB); any count >= 4
+  const uint32_t nfullchunks = (uint32_t)(n / chunk);
+  const bool fast = V >= 4u && (chunk32 & 4095u) == 0 && (((uintptr_t)in) & 15u) == 0 && nfullchunks > 0;
+  auto vptr = [&](uint32_t c, uint32_t j) -> const uint4* {
+    if (c >= nfullchunks) c = nfullchunks - 1;  // past the end: redundant, harmless loads
+    return reinterpret_cast<const uint4*>(in + (uint64_t)c * chunk) + (uint64_t)j * kHistThreads + tid;
+  };
+  uint4 A = make_uint4(0, 0, 0, 0), B = A;
+  if (fast) {
+    // non-temporal loads: the input streams past the Infinity Cache instead of through it (4 GiB: 0.79 -> 0.69 ms, i.e.
+    // 6.2 TB/s of reads; nothing changes at 256 MiB, where the pipelined neighbours' write-backs set the pace)
+    A = load_stream(vptr(blockIdx.x, 0));
+    B = load_stream(vptr(blockIdx.x, 1));
+  }
+  for (uint32_t i = tid; i < 256 * kHistRep; i += kHistThreads) lh[i] = 0;
+  __syncthreads();
 
   __shared__ uint32_t s_tick;
   // end of a chunk: thread t sums the 32 replicas of bin t (rotated start: 32 lanes on 32 banks); the counters
@@ -70,9 +86,6 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
   // keeps a late or slow workgroup from becoming the kernel's straggler.  Per thread the vectors of consecutive
   // chunks form ONE stream: four 16-byte loads are always in flight (A/B and C/D alternate, no register copies),
   // also across the chunk boundary -- the next chunk's first vectors are requested while this one is reduced.
-  const uint32_t V = chunk32 >> 12;  // vectors per thread per chunk (256 threads x 16 B = 4 KiB); any count >= 4
-  const uint32_t nfullchunks = (uint32_t)(n / chunk);
-  const bool fast = V >= 4u && (chunk32 & 4095u) == 0 && (((uintptr_t)in) & 15u) == 0 && nfullchunks > 0;
   if (fast) {
     // (a class's workgroups sit on all eight XCDs -- consecutive workgroups go to consecutive XCDs -- so that no XCD is
     //  tied to a fixed share of the chunks; see k_decode)
@@ -84,16 +97,9 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
     auto draw = [&]() -> uint32_t { return 2u * gridDim.x + (uint32_t)atomicAdd(tick, 1ull) * ncls + cls; };  // thread 0 only
     uint32_t cur = blockIdx.x;
     uint32_t nxt = blockIdx.x + gridDim.x;
-    auto vptr = [&](uint32_t c, uint32_t j) -> const uint4* {
-      if (c >= nfullchunks) c = nfullchunks - 1;  // past the end: redundant, harmless loads
-      return reinterpret_cast<const uint4*>(in + (uint64_t)c * chunk) + (uint64_t)j * kHistThreads + tid;
-    };
     // vector g of the thread's STREAM: the chunk's own vectors, then the next chunk's
     auto vat = [&](uint32_t g) -> const uint4* { return g < V ? vptr(cur, g) : vptr(nxt, g - V); };
     const uint32_t Vmain = V & ~3u, Vrest = V & 3u;  // (wave-uniform, the same for every chunk of the launch)
-    // non-temporal loads: the input streams past the Infinity Cache instead of through it (4 GiB: 0.79 -> 0.69 ms, i.e.
-    // 6.2 TB/s of reads; nothing changes at 256 MiB, where the pipelined neighbours' write-backs set the pace)
-    uint4 A = load_stream(vptr(cur, 0)), B = load_stream(vptr(cur, 1));
     while (cur < nfullchunks) {
       uint32_t t_next = 0;
       if (tid == 0) t_next = draw();  // the chunk after next; the atomic returns long before it is needed
@@ -170,10 +176,14 @@ __global__ __launch_bounds__(kHistThreads) void k_histogram(const uint8_t* __res
   }
   __syncthreads();
   if (s_last) {
+    // all 32 replica loads in flight at once (one L2 round trip at the very end of the launch, not four), then the stores
+    unsigned long long part[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) part[r] = __hip_atomic_load(&acc[r * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long sum = 0;
-#pragma unroll 8
+#pragma unroll
     for (int r = 0; r < 32; ++r) {
-      sum += __hip_atomic_load(&acc[r * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sum += part[r];
       __hip_atomic_store(&acc[r * 256 + tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     hist[tid] = add ? hist[tid] + sum : sum;
