@@ -202,6 +202,25 @@ def test_emit_main_loops_have_counted_waits_and_no_scratch():
     assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) == 0
 
 
+def test_histogram_epilogue_keeps_its_replica_loads_in_flight():
+    """K1 (k_histogram).  The launch's last workgroup sums 32 replicas of the totals with agent-scope loads and zeroes them.
+    Written as one loop over (load, store) pairs the compiler chained them -- a full wait behind every few loads, up to 32 L2
+    round trips at the very end of a 55 us launch (8-10 us of it, profiles/r04/experiments/k1_k5_launch_edges.txt).  Now all
+    32 loads are issued before the first store: between the first and the last of them no wait drains the queue (the counted
+    waits the compiler puts there -- it starts adding while it still issues -- leave at least six loads outstanding)."""
+    text = _kernel_asm("ghf_kernels")
+    sym = "_ZN3ghf11k_histogramEPKhmjjPjPyS3_j"
+    body = text[text.index(sym + ":"):]
+    body = body[: body.index(".Lfunc_end")].split("\n")
+    loads = [i for i, l in enumerate(body) if re.search(r"global_load_dwordx2 .*\bsc1\b", l)]
+    assert len(loads) >= 32, len(loads)
+    run = loads[-32:]  # the epilogue's 32 replica loads are the function's last agent-scope loads
+    between = body[run[0]: run[-1] + 1]
+    assert not any(re.search(r"global_store|global_atomic", l) for l in between), "a store between the replica loads"
+    waits = [int(w) for l in between for w in re.findall(r"s_waitcnt.*vmcnt\((\d+)\)", l)]
+    assert all(w >= 6 for w in waits), waits
+
+
 def test_k6_kernels_use_no_scratch():
     """Twice now a build of one of these LDS-heavy kernels that SPILLED gave wrong streams on the GPU where its non-spilling
     twin did not (round 1: k_emit with 6 spilled VGPRs; round 3: k_sync_table with 4, the build that read both candidate
